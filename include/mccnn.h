@@ -1,0 +1,128 @@
+/*
+ * mccnn.h - C ABI of libmccnn_hip.so: the MI355X (gfx950) stereo-matching hot path.
+ *
+ * The reference (Jackie-Chou/MC-CNN-python) has no FFI layer: its hot path is eleven NumPy functions in
+ * src/process_functional.py called by src/match.py:132-175.  Each entry point below replaces the interpreted
+ * loop nest of one of those functions; the host-side mirror in mc-cnn-python_amd/src/process_functional.py keeps
+ * the reference's Python signatures and calls these through ctypes (see INTEGRATION.md for the binding).
+ * "pf:" = /root/reference/src/process_functional.py.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) owned by the caller; nothing is retained after return
+ *   - no allocation, no synchronisation: work is enqueued on `stream` (a hipStream_t passed as void*);
+ *     scratch, where needed, is passed in and sized by the matching *_scratch_bytes() query
+ *   - return 0 on success, otherwise a negative MCCNN_E_* code or the positive hipError_t of the failed launch;
+ *     mccnn_last_error_string() describes the last failure on the calling thread
+ *   - float32 everywhere (the reference's dtype); sizes are ints, byte offsets are 64-bit inside
+ *
+ * HBM layouts
+ *   image     [H][W]        float32 (the reference's [H,W,1])
+ *   features  [H][W][C]     float32, C = 64 (NET.features, NHWC)
+ *   volume    "DHW" [D][H][W]   - the reference's layout; cost volume, CBCA, WTA, sub-pixel use it
+ *             "HWD" [H][W][Dp]  - pixel-major, Dp = mccnn_hwd_pitch(D); the SGM scanline kernels use it
+ *   arms      [H][W][4]     uint8  (up, down, left, right) cross-arm lengths, self excluded
+ *   maps      [H][W]        float32 disparity maps, int32 status / region counts
+ */
+#ifndef MCCNN_H
+#define MCCNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *mccnn_stream_t; /* hipStream_t */
+
+#define MCCNN_ABI_VERSION 1
+
+#define MCCNN_E_INVALID (-1)     /* bad argument (null pointer, non-positive size, unsupported shape) */
+#define MCCNN_E_UNSUPPORTED (-2) /* shape outside what the kernels were built for (e.g. D > 512 for SGM) */
+#define MCCNN_E_SCRATCH (-3)     /* scratch buffer too small */
+
+#define MCCNN_SIDE_LEFT 0  /* the reference's choice == "L" */
+#define MCCNN_SIDE_RIGHT 1 /* choice == "R" */
+
+int mccnn_version(void);
+const char *mccnn_last_error_string(void);
+
+/* ---- a2  compute_cost_volume (pf:78-113) ------------------------------------------------------------------
+ * lcv[d,h,w] = -<fl[h,w,:], fr[h,w-d,:]> for w >= d, border columns filled by the reference's 3-tap mean
+ * recurrences, rcv[d,h,w] = lcv[d,h,w+d] (+ its own border recurrence).  Requires 1 <= D <= W-2.
+ * mode MCCNN_CV_EXACT reproduces NumPy's pairwise float32 summation order bit for bit (C must be 64);
+ * mode MCCNN_CV_MFMA contracts the 64 channels on the matrix cores (v_mfma_f32_32x32x2_f32, fma-chain order,
+ * |diff| <= 2e-6 on unit-norm features). */
+#define MCCNN_CV_EXACT 0
+#define MCCNN_CV_MFMA 1
+int mccnn_cost_volume(const float *fl, const float *fr, int H, int W, int C, int D, float *lcv, float *rcv, int mode,
+                      mccnn_stream_t stream);
+
+/* ---- a3  compute_cross_region (pf:571-657) ----------------------------------------------------------------
+ * Arm lengths (<= L-1 per side, anchor-relative threshold |I(q)-I(p)| < tau) and the region size
+ * count[h,w] = sum over the vertical arm of (left+right+1).  The reference's explicit coordinate list
+ * [H][W][(2L)^2][2] (padded with -1) is produced by mccnn_cross_region_list for API compatibility only. */
+int mccnn_cross_arms(const float *image, int H, int W, float tau, int L, uint8_t *arms, int32_t *count,
+                     mccnn_stream_t stream);
+int mccnn_cross_region_list(const uint8_t *arms, int H, int W, int L, int32_t *region, mccnn_stream_t stream);
+
+/* ---- a4  cost_volume_aggregation, ONE iteration on ONE volume (pf:149-163) -----------------------------------
+ * out[d,p] = (sum_{q in U(p)} in[d,q]) / count[p];  in != out (ping-pong; the reference does not mutate either).
+ * L is the distance threshold the arms were built with (arms < L; supported: L <= 32).
+ * order MCCNN_CBCA_SEPARABLE: horizontal-arm sums then vertical-arm sums (same set, float32 rounding differs
+ * from the reference by <= 1e-6 per iteration on O(1) costs); MCCNN_CBCA_REFERENCE_ORDER: the reference's flat
+ * running sum (vertical arm self,up..,down.. x horizontal arm self,left..,right..), bit-exact, slower. */
+#define MCCNN_CBCA_SEPARABLE 0
+#define MCCNN_CBCA_REFERENCE_ORDER 1
+int mccnn_cbca_iter(const float *in, float *out, const uint8_t *arms, const int32_t *count, int D, int H, int W,
+                    int L, int order, mccnn_stream_t stream);
+
+/* ---- layout changes between DHW and HWD ------------------------------------------------------------------- */
+int mccnn_hwd_pitch(int D); /* Dp: D rounded up to a multiple of 4 (16-byte rows) */
+int mccnn_dhw_to_hwd(const float *dhw, float *hwd, int D, int H, int W, mccnn_stream_t stream);
+int mccnn_hwd_to_dhw(const float *hwd, float *dhw, int D, int H, int W, mccnn_stream_t stream);
+
+/* ---- a6  semi_global_matching, one axis-aligned direction, in place (pf:476-568) -----------------------------
+ * vol_hwd is updated in place along r = (rh, rw) in {(0,1),(0,-1),(-1,0),(1,0)}; the first line of the scan
+ * axis is left untouched.  Penalties are recomputed from the two images (no P1/P2/D2 volumes):
+ *   (P1,P2) = (p1,p2) if D1<thr and D2<thr; /q2 if both >= thr; /q1 otherwise      (pf:535-541)
+ * p1, p2, q1, q2, thr are the float32 roundings NumPy applies to the Python scalars (pass float(sgm_P1/sgm_V)
+ * as p1 for the vertical directions, pf:204).  float32 add/min/sub only, un-fused: bit-exact vs the reference.
+ * Up to two volumes (e.g. left + right) are advanced by one launch so the chip sees 2x the scanlines:
+ * n_jobs in {1,2}; job j updates vol_hwd[j] as side[j].  scratch >= mccnn_sgm_scratch_bytes(H,W,D). 2<=D<=512. */
+size_t mccnn_sgm_scratch_bytes(int H, int W, int D);
+int mccnn_sgm_pass(const float *image_left, const float *image_right, float *const *vol_hwd, const int *side,
+                   int n_jobs, int D, int H, int W, int rh, int rw, float p1, float p2, float q1, float q2, float thr,
+                   void *scratch, size_t scratch_bytes, mccnn_stream_t stream);
+
+/* ---- a7  disparity_prediction, one volume (pf:239-272): first strict minimum over d, as float32 -------------- */
+int mccnn_wta(const float *vol_dhw, int D, int H, int W, float *disparity, mccnn_stream_t stream);
+
+/* ---- a8  interpolation (pf:279-378) -------------------------------------------------------------------------
+ * mccnn_lr_status: 0 match, 1 mismatch, 2 occlusion (pf:285-307).  mccnn_interpolate: status 1 -> median of the
+ * nearest status-0 pixel right/left/below/above, status 2 -> nearest status-0 pixel to the right, else raw. */
+int mccnn_lr_status(const float *disp_left, const float *disp_right, int H, int W, int D, int32_t *status,
+                    mccnn_stream_t stream);
+int mccnn_interpolate(const float *disp_left, const int32_t *status, int H, int W, float *out,
+                      mccnn_stream_t stream);
+
+/* ---- a9  subpixel_enhance (pf:381-400), float32 as NumPy 2 evaluates it ------------------------------------- */
+int mccnn_subpixel(const float *disp, const float *vol_dhw, int D, int H, int W, float *out, mccnn_stream_t stream);
+
+/* ---- a10 median_filter (pf:403-421): clipped fh x fw window (odd sizes, fh*fw <= 49), np.median ------------- */
+int mccnn_median(const float *disp, int H, int W, int fh, int fw, float *out, mccnn_stream_t stream);
+
+/* ---- a11 bilateral_filter (pf:424-470) ----------------------------------------------------------------------
+ * table: device [fh][fw] float32 spatial kernel (util.normal evaluated on the host, pf:428-436); thr gates
+ * |I(q)-I(p)| < thr.  Sums follow NumPy's pairwise order over the clipped window (pf:463,466): bit-exact. */
+int mccnn_bilateral(const float *image, const float *disp, int H, int W, int fh, int fw, const float *table,
+                    float thr, float *out, mccnn_stream_t stream);
+
+/* ---- a1 epilogue: tf.nn.l2_normalize over channels (model.py:64), x * rsqrt(max(sum x^2, 1e-12)) -----------
+ * in: NCHW [C][H][W] (what the PyTorch-ROCm conv stack produces) -> out: NHWC [H][W][C] unit vectors. */
+int mccnn_l2norm_chw_to_hwc(const float *chw, float *hwc, int C, int H, int W, mccnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCCNN_H */

@@ -1,0 +1,224 @@
+// a2  compute_cost_volume (/root/reference/src/process_functional.py:78-113) on gfx950.
+//
+//   lcv[d,h,w] = -<fl[h,w,:], fr[h,w-d,:]>            w >= d          (pf:87-91, 111)
+//   lcv[d,h,w] = mean(lcv[d,h,w+1..w+3])               w <  d, right-to-left recurrence   (pf:94-95)
+//   rcv[d,h,w] = lcv[d,h,w+d]                          w <  W-d        (pf:103-104)
+//   rcv[d,h,w] = mean(rcv[d,h,w-3..w-1])               w >= W-d, left-to-right recurrence (pf:105-106)
+//
+// The score matrix of one image row, S[w,w'] = <fl[w], fr[w']>, is a banded product (0 <= w-w' < D); every
+// entry feeds lcv[d,h,w] and rcv[d,h,w'] (d = w-w'), both contiguous in w for fixed d, so a workgroup that owns
+// 64 columns x 64 disparities of one row writes 256-B runs into both volumes.  Bound: HBM writes (8 B/voxel for
+// 128 flop/voxel).  The recurrences run on the already negated values: the mean is linear and rounding is
+// sign-symmetric, so the bits equal the reference's fill-then-negate.
+//
+// MCCNN_CV_EXACT  : VALU kernel that reproduces NumPy's float32 pairwise summation of the 64 products
+//                   (8 running sums, fixed combine tree - numpy loops_utils pairwise_sum) bit for bit.
+// MCCNN_CV_MFMA   : the 64-channel contraction on the matrix cores, v_mfma_f32_32x32x2_f32 (exact-f32 fma chain in
+//                   channel order); differs from NumPy's order by <= 2e-6 on unit-norm features.
+#include "common.h"
+
+namespace mccnn {
+
+constexpr int CV_TW = 64;   // output columns per workgroup
+constexpr int CV_DT = 64;   // disparities per workgroup
+constexpr int CV_C = 64;    // feature channels (NET num_conv_feature_maps)
+constexpr int CV_LD = 68;   // padded LDS row (floats): 16-B slot index = (row + c4) mod 16 -> conflict-free b128
+
+__global__ __launch_bounds__(256) void cost_volume_exact_kernel(const float *__restrict__ fl,
+                                                                const float *__restrict__ fr, int H, int W, int D,
+                                                                float *__restrict__ lcv, float *__restrict__ rcv)
+{
+    __shared__ __attribute__((aligned(16))) float sR[(CV_TW + CV_DT - 1) * CV_LD];
+    __shared__ __attribute__((aligned(16))) float sL[CV_TW * CV_LD];
+    const int w0 = blockIdx.x * CV_TW, h = blockIdx.y, d0 = blockIdx.z * CV_DT;
+    if (w0 + CV_TW - 1 < d0) return;  // every (w, d) of this tile has w < d: border fill handles it
+    const int tid = threadIdx.x;
+    const size_t rowbase = (size_t)h * W;
+    for (int i = tid; i < CV_TW * 16; i += 256) {
+        const int px = i >> 4, c4 = i & 15;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (w0 + px < W) v = *reinterpret_cast<const float4 *>(fl + (rowbase + w0 + px) * CV_C + c4 * 4);
+        *reinterpret_cast<float4 *>(&sL[px * CV_LD + c4 * 4]) = v;
+    }
+    const int xr0 = w0 - d0 - (CV_DT - 1);  // right-image column held in sR row 0
+    for (int i = tid; i < (CV_TW + CV_DT - 1) * 16; i += 256) {
+        const int r = i >> 4, c4 = i & 15;
+        const int x = xr0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (x >= 0 && x < W) v = *reinterpret_cast<const float4 *>(fr + (rowbase + x) * CV_C + c4 * 4);
+        *reinterpret_cast<float4 *>(&sR[r * CV_LD + c4 * 4]) = v;
+    }
+    __syncthreads();
+
+    const int wl = tid & 63, dq = tid >> 6;  // dq is wave-uniform: each wave owns 16 disparities
+    const int w = w0 + wl;
+    float a[CV_C];
+#pragma unroll
+    for (int c4 = 0; c4 < 16; ++c4) {
+        const float4 v = *reinterpret_cast<const float4 *>(&sL[wl * CV_LD + c4 * 4]);
+        a[c4 * 4 + 0] = v.x; a[c4 * 4 + 1] = v.y; a[c4 * 4 + 2] = v.z; a[c4 * 4 + 3] = v.w;
+    }
+    const size_t plane = (size_t)H * W;
+    for (int k = 0; k < 16; ++k) {
+        const int d = d0 + dq * 16 + k;
+        if (d >= D) break;
+        const int r = wl + (CV_DT - 1) - (dq * 16 + k);  // sR row of right column w - d
+        if (w < W && w >= d) {
+            const float *b = &sR[r * CV_LD];
+            float acc[8];
+            // numpy pairwise_sum, n = 64: r[j] = p[j]; r[j] += p[8i+j]; ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float4 b0 = *reinterpret_cast<const float4 *>(b + i * 8);
+                const float4 b1 = *reinterpret_cast<const float4 *>(b + i * 8 + 4);
+                const float p0 = a[i * 8 + 0] * b0.x, p1 = a[i * 8 + 1] * b0.y, p2 = a[i * 8 + 2] * b0.z,
+                            p3 = a[i * 8 + 3] * b0.w, p4 = a[i * 8 + 4] * b1.x, p5 = a[i * 8 + 5] * b1.y,
+                            p6 = a[i * 8 + 6] * b1.z, p7 = a[i * 8 + 7] * b1.w;
+                if (i == 0) {
+                    acc[0] = p0; acc[1] = p1; acc[2] = p2; acc[3] = p3;
+                    acc[4] = p4; acc[5] = p5; acc[6] = p6; acc[7] = p7;
+                } else {
+                    acc[0] += p0; acc[1] += p1; acc[2] += p2; acc[3] += p3;
+                    acc[4] += p4; acc[5] += p5; acc[6] += p6; acc[7] += p7;
+                }
+            }
+            float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+            s = 0.f + s;  // np.sum adds the pairwise result to the identity
+            s = -1.f * s;
+            lcv[(size_t)d * plane + rowbase + w] = s;
+            rcv[(size_t)d * plane + rowbase + (w - d)] = s;
+        }
+    }
+}
+
+// ---- MFMA variant ---------------------------------------------------------------------------------------------
+// One wave computes a 32(w) x 32(w') block of S with 32 x v_mfma_f32_32x32x2_f32 (K = 64 channels, 2 per issue).
+// A operand: lane l holds fl[w = l&31][k = l>>5]; B operand: fr[w' = l&31][k = l>>5]; C/D: col = lane&31 (w'),
+// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (w).  A workgroup of 4 waves covers 64 w x 64 w' and keeps only the
+// band 0 <= w-w' < D.  The accumulator is staged through LDS so that stores run along w for fixed d.
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int CVM_LD = 66;  // LDS pitch of the 64x64 S tile (floats)
+constexpr int CVM_PL = 65;  // LDS pitch of the operand tiles: bank = (row + k) mod 32 -> conflict-free ds_read_b32
+
+__global__ __launch_bounds__(256) void cost_volume_mfma_kernel(const float *__restrict__ fl,
+                                                               const float *__restrict__ fr, int H, int W, int D,
+                                                               float *__restrict__ lcv, float *__restrict__ rcv)
+{
+    __shared__ float sL[64 * CVM_PL];
+    __shared__ float sR[64 * CVM_PL];
+    __shared__ float sS[64 * CVM_LD];
+    // tile (bw, bx): left columns w0..w0+63, right columns x0..x0+63; d = w - x in (w0-x0-63 .. w0-x0+63)
+    const int h = blockIdx.y;
+    const int w0 = blockIdx.x * 64;
+    const int x0 = w0 - (int)blockIdx.z * 64;  // blockIdx.z = band index: 0 -> x0 = w0, 1 -> x0 = w0-64, ...
+    if (x0 + 63 < 0) return;
+    if (w0 - x0 - 63 >= D) return;
+    const int tid = threadIdx.x;
+    const size_t rowbase = (size_t)h * W;
+    for (int i = tid; i < 64 * 16; i += 256) {
+        const int px = i >> 4, c4 = i & 15;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f), u = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (w0 + px < W) v = *reinterpret_cast<const float4 *>(fl + (rowbase + w0 + px) * CV_C + c4 * 4);
+        const int x = x0 + px;
+        if (x >= 0 && x < W) u = *reinterpret_cast<const float4 *>(fr + (rowbase + x) * CV_C + c4 * 4);
+        float *dl = &sL[px * CVM_PL + c4 * 4], *dr = &sR[px * CVM_PL + c4 * 4];
+        dl[0] = v.x; dl[1] = v.y; dl[2] = v.z; dl[3] = v.w;
+        dr[0] = u.x; dr[1] = u.y; dr[2] = u.z; dr[3] = u.w;
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;  // this wave's 32x32 sub-block (w rows, x cols)
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const float *pa = &sL[(wr + (lane & 31)) * CVM_PL + (lane >> 5)];
+    const float *pb = &sR[(wc + (lane & 31)) * CVM_PL + (lane >> 5)];
+#pragma unroll
+    for (int k = 0; k < CV_C; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k], pb[k], acc, 0, 0, 0);
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+        const int row = (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
+        sS[(wr + row) * CVM_LD + wc + (lane & 31)] = acc[rg];
+    }
+    __syncthreads();
+    // Store along w for fixed d: 127 diagonals of the 64x64 tile; thread t walks diagonal-major so that
+    // consecutive lanes write consecutive w (and consecutive w' = w - d).
+    const size_t plane = (size_t)H * W;
+    const int dbase = w0 - x0;  // d of the main diagonal
+    for (int diag = wave; diag < 127; diag += 4) {
+        const int dd = diag - 63;      // w_local - x_local
+        const int d = dbase + dd;
+        if (d < 0 || d >= D) continue;
+        const int wl = lane;           // w_local
+        const int xl = wl - dd;        // x_local
+        if (xl < 0 || xl >= 64) continue;
+        const int w = w0 + wl, x = x0 + xl;
+        if (w >= W || x < 0) continue;
+        const float s = -1.f * sS[wl * CVM_LD + xl];
+        lcv[(size_t)d * plane + rowbase + w] = s;
+        rcv[(size_t)d * plane + rowbase + x] = s;
+    }
+}
+
+// Border recurrences on the negated volumes.  One thread per (d, h); <= d sequential 3-tap steps each.
+__global__ __launch_bounds__(256) void cost_volume_fill_kernel(float *__restrict__ lcv, float *__restrict__ rcv,
+                                                               int D, int H, int W)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= D * H) return;
+    const int d = idx / H, h = idx - d * H;
+    if (d == 0) return;
+    float *L = lcv + ((size_t)d * H + h) * W;
+    float *R = rcv + ((size_t)d * H + h) * W;
+    {   // pf:94-95: column w = d-1 .. 0 from columns w+1, w+2, w+3 (NumPy sums them in ascending order)
+        float x1 = L[d], x2 = L[d + 1], x3 = L[d + 2];
+        for (int w = d - 1; w >= 0; --w) {
+            float s = 0.f + x1;
+            s = s + x2;
+            s = s + x3;
+            const float v = s / 3.f;
+            L[w] = v;
+            x3 = x2; x2 = x1; x1 = v;
+        }
+    }
+    {   // pf:105-106: column w = W-d .. W-1 from columns w-3, w-2, w-1
+        float x1 = R[W - d - 3], x2 = R[W - d - 2], x3 = R[W - d - 1];
+        for (int w = W - d; w < W; ++w) {
+            float s = 0.f + x1;
+            s = s + x2;
+            s = s + x3;
+            const float v = s / 3.f;
+            R[w] = v;
+            x1 = x2; x2 = x3; x3 = v;
+        }
+    }
+}
+
+}  // namespace mccnn
+
+extern "C" int mccnn_cost_volume(const float *fl, const float *fr, int H, int W, int C, int D, float *lcv, float *rcv,
+                                 int mode, mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(fl && fr && lcv && rcv, MCCNN_E_INVALID, "mccnn_cost_volume: null pointer");
+    MCCNN_REQUIRE(H > 0 && W > 0 && D > 0, MCCNN_E_INVALID, "mccnn_cost_volume: non-positive size");
+    MCCNN_REQUIRE(C == CV_C, MCCNN_E_UNSUPPORTED, "mccnn_cost_volume: C=%d, kernels are built for 64 channels", C);
+    MCCNN_REQUIRE(D <= W - 2, MCCNN_E_UNSUPPORTED,
+                  "mccnn_cost_volume: D=%d needs W >= D+2 (the reference's border recurrence pf:106 is degenerate "
+                  "beyond that), W=%d", D, W);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 block(256);
+    if (mode == MCCNN_CV_EXACT) {
+        const dim3 grid(cdiv(W, CV_TW), H, cdiv(D, CV_DT));
+        hipLaunchKernelGGL(cost_volume_exact_kernel, grid, block, 0, s, fl, fr, H, W, D, lcv, rcv);
+    } else if (mode == MCCNN_CV_MFMA) {
+        const dim3 grid(cdiv(W, 64), H, cdiv(D + 63, 64) + 1);
+        hipLaunchKernelGGL(cost_volume_mfma_kernel, grid, block, 0, s, fl, fr, H, W, D, lcv, rcv);
+    } else {
+        MCCNN_REQUIRE(false, MCCNN_E_INVALID, "mccnn_cost_volume: unknown mode %d", mode);
+    }
+    int rc = check_launch("mccnn_cost_volume");
+    if (rc) return rc;
+    hipLaunchKernelGGL(cost_volume_fill_kernel, dim3(cdiv((long)D * H, 256)), block, 0, s, lcv, rcv, D, H, W);
+    return check_launch("mccnn_cost_volume(fill)");
+}

@@ -1,0 +1,302 @@
+// a7-a11 of the hot path (/root/reference/src/process_functional.py:239-470) and the feature-head epilogue
+// (model.py:64) on gfx950.  All of these touch O(H*W) data except WTA / sub-pixel, which stream the DHW volume.
+#include "common.h"
+
+namespace mccnn {
+
+// ---- a7 disparity_prediction (pf:245-254): first strict minimum -------------------------------------------------
+// Adjacent lanes own adjacent columns, so every plane row is read in 256-B runs; 8 B/voxel for both volumes.
+__global__ __launch_bounds__(256) void wta_kernel(const float *__restrict__ vol, int D, long N,
+                                                  float *__restrict__ disp)
+{
+    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float best = __builtin_huge_valf();
+    int bd = -1;
+    const float *p = vol + n;
+    int d = 0;
+    for (; d + 4 <= D; d += 4) {
+        const float v0 = p[(size_t)(d + 0) * N], v1 = p[(size_t)(d + 1) * N], v2 = p[(size_t)(d + 2) * N],
+                    v3 = p[(size_t)(d + 3) * N];
+        if (v0 < best) { best = v0; bd = d; }
+        if (v1 < best) { best = v1; bd = d + 1; }
+        if (v2 < best) { best = v2; bd = d + 2; }
+        if (v3 < best) { best = v3; bd = d + 3; }
+    }
+    for (; d < D; ++d) {
+        const float v = p[(size_t)d * N];
+        if (v < best) { best = v; bd = d; }
+    }
+    disp[n] = (float)bd;  // pf:254 stores the index into a float32 map (-1 only if every cost is NaN/+inf)
+}
+
+// ---- a8 interpolation (pf:279-378) ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lr_status_kernel(const float *__restrict__ dl, const float *__restrict__ dr,
+                                                        int H, int W, int D, int32_t *__restrict__ status)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    const int h = blockIdx.y;
+    if (w >= W) return;
+    const float *drow = dr + (size_t)h * W;
+    const int ld = (int)dl[(size_t)h * W + w];  // pf:287 int() truncation
+    int st;
+    if (w < ld) {
+        st = 2;  // pf:289-291
+    } else if (fabsf((float)ld - drow[w - ld]) <= 1.f) {
+        st = 0;  // pf:294
+    } else {
+        st = 2;
+        const int lim = min(w + 1, D);
+        for (int d = 0; d < lim; ++d)
+            if (fabsf((float)d - drow[w - d]) <= 1.f) { st = 1; break; }  // pf:299-303
+    }
+    status[(size_t)h * W + w] = st;
+}
+
+__device__ __forceinline__ float median_upto4(float *v, int n)
+{
+    // np.median of 1..4 float32 values: sort, middle element or mean of the two middle ones
+    for (int i = 1; i < n; ++i) {
+        const float x = v[i];
+        int j = i - 1;
+        while (j >= 0 && v[j] > x) { v[j + 1] = v[j]; --j; }
+        v[j + 1] = x;
+    }
+    if (n & 1) return v[n >> 1];
+    return (v[(n >> 1) - 1] + v[n >> 1]) / 2.f;
+}
+
+__global__ __launch_bounds__(256) void interpolate_kernel(const float *__restrict__ dl,
+                                                          const int32_t *__restrict__ st, int H, int W,
+                                                          float *__restrict__ out)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    const int h = blockIdx.y;
+    if (w >= W) return;
+    const size_t p = (size_t)h * W + w;
+    const int s = st[p];
+    float res = dl[p];
+    if (s == 1) {  // pf:316-356: nearest match right, left, below, above (reads the raw map only)
+        float nb[4];
+        int c = 0;
+        for (int x = w + 1; x < W; ++x) if (st[(size_t)h * W + x] == 0) { nb[c++] = dl[(size_t)h * W + x]; break; }
+        for (int x = w - 1; x >= 0; --x) if (st[(size_t)h * W + x] == 0) { nb[c++] = dl[(size_t)h * W + x]; break; }
+        for (int y = h + 1; y < H; ++y) if (st[(size_t)y * W + w] == 0) { nb[c++] = dl[(size_t)y * W + w]; break; }
+        for (int y = h - 1; y >= 0; --y) if (st[(size_t)y * W + w] == 0) { nb[c++] = dl[(size_t)y * W + w]; break; }
+        if (c > 0) res = median_upto4(nb, c);
+    } else if (s == 2) {  // pf:358-373: nearest match to the right
+        for (int x = w + 1; x < W; ++x) if (st[(size_t)h * W + x] == 0) { res = dl[(size_t)h * W + x]; break; }
+    }
+    out[p] = res;
+}
+
+// ---- a9 subpixel_enhance (pf:387-396) ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void subpixel_kernel(const float *__restrict__ dl, const float *__restrict__ vol,
+                                                       int D, long N, float *__restrict__ out)
+{
+    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float d = dl[n];
+    const int im = (int)(d - 1.f), ip = (int)(d + 1.f), ic = (int)d;
+    float res = d;
+    if (!(im < 0 || ip >= D)) {
+        const float cm = vol[(size_t)im * N + n], cp = vol[(size_t)ip * N + n], c = vol[(size_t)ic * N + n];
+        const float num = cp - cm;
+        float den = cp - 2.f * c;
+        den = den + cm;
+        den = 2.f * den;
+        res = d - num / den;
+    }
+    out[n] = res;
+}
+
+// ---- a10 median_filter (pf:409-417) -----------------------------------------------------------------------------
+constexpr int MAXWIN = 49;
+
+__global__ __launch_bounds__(256) void median_kernel(const float *__restrict__ dl, int H, int W, int fh, int fw,
+                                                     float *__restrict__ out)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    const int h = blockIdx.y;
+    if (w >= W) return;
+    const int rh = (fh - 1) / 2, rw = (fw - 1) / 2;
+    const int hs = max(0, h - rh), he = min(H, h + rh + 1), ws = max(0, w - rw), we = min(W, w + rw + 1);
+    float v[MAXWIN];
+    int n = 0;
+    bool has_nan = false;
+    for (int y = hs; y < he; ++y)
+        for (int x = ws; x < we; ++x) {
+            const float t = dl[(size_t)y * W + x];
+            has_nan |= (t != t);
+            // insertion keeps v[0..n) sorted ascending
+            int j = n - 1;
+            while (j >= 0 && v[j] > t) { v[j + 1] = v[j]; --j; }
+            v[j + 1] = t;
+            ++n;
+        }
+    float res;
+    if (has_nan) res = __builtin_nanf("");  // np.median propagates NaN
+    else if (n & 1) res = v[n >> 1];
+    else res = (v[(n >> 1) - 1] + v[n >> 1]) / 2.f;  // np.mean of the two middle float32 values
+    out[(size_t)h * W + w] = res;
+}
+
+// ---- a11 bilateral_filter (pf:440-466) --------------------------------------------------------------------------
+// NumPy float32 add.reduce over n contiguous values (pairwise_sum, n <= 128), then + identity.
+__device__ __forceinline__ float np_sum_small(const float *a, int n)
+{
+    float res;
+    if (n < 8) {
+        res = 0.f;
+        for (int i = 0; i < n; ++i) res += a[i];
+    } else {
+        float r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        int i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+    }
+    return 0.f + res;
+}
+
+__global__ __launch_bounds__(256) void bilateral_kernel(const float *__restrict__ img, const float *__restrict__ dl,
+                                                        int H, int W, int fh, int fw, const float *__restrict__ table,
+                                                        float thr, float *__restrict__ out)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    const int h = blockIdx.y;
+    if (w >= W) return;
+    const int ch = (fh - 1) / 2, cw = (fw - 1) / 2;
+    const int hs = max(0, h - ch), he = min(H, h + ch + 1), ws = max(0, w - cw), we = min(W, w + cw + 1);
+    const float cur = img[(size_t)h * W + w];
+    float wgt[MAXWIN], val[MAXWIN];
+    int n = 0;
+    for (int y = hs; y < he; ++y)
+        for (int x = ws; x < we; ++x) {
+            const float t = img[(size_t)y * W + x] - cur;
+            const float sq = t * t;
+            const float diff = sqrtf(sq);                                   // pf:458-459
+            const float gate = diff < thr ? 1.f : 0.f;                      // pf:460
+            const float f = gate * table[(ch + (y - h)) * fw + (cw + (x - w))];  // pf:462
+            wgt[n] = f;
+            val[n] = f * dl[(size_t)y * W + x];                             // pf:465
+            ++n;
+        }
+    const float wsum = np_sum_small(wgt, n);  // pf:463
+    const float vsum = np_sum_small(val, n);  // pf:466
+    out[(size_t)h * W + w] = vsum / wsum;
+}
+
+// ---- a1 epilogue: tf.nn.l2_normalize(dim=-1) (model.py:64), NCHW in -> NHWC out ---------------------------------
+// 64 pixels x C channels per workgroup through a padded LDS tile: plane rows are read in 256-B runs and each pixel's
+// C-vector is written as one contiguous run.
+template <int C>
+__global__ __launch_bounds__(256) void l2norm_chw_to_hwc_kernel(const float *__restrict__ chw, float *__restrict__ hwc,
+                                                                long N)
+{
+    __shared__ float tile[C][65];
+    __shared__ float scale[64];
+    const long n0 = (long)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int c = ty; c < C; c += 4) tile[c][tx] = (n0 + tx < N) ? chw[(size_t)c * N + n0 + tx] : 0.f;
+    __syncthreads();
+    if (ty == 0) {
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s = fmaf(tile[c][tx], tile[c][tx], s);
+        s = fmaxf(s, 1e-12f);
+        scale[tx] = 1.f / sqrtf(s);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * C; i += 256) {
+        const int px = i / C, c = i - px * C;
+        if (n0 + px < N) hwc[(size_t)(n0 + px) * C + c] = tile[c][px] * scale[px];
+    }
+}
+
+}  // namespace mccnn
+
+extern "C" int mccnn_wta(const float *vol_dhw, int D, int H, int W, float *disparity, mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(vol_dhw && disparity, MCCNN_E_INVALID, "mccnn_wta: null pointer");
+    MCCNN_REQUIRE(D > 0 && H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_wta: non-positive size");
+    const long N = (long)H * W;
+    hipLaunchKernelGGL(wta_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, vol_dhw, D, N, disparity);
+    return check_launch("mccnn_wta");
+}
+
+extern "C" int mccnn_lr_status(const float *disp_left, const float *disp_right, int H, int W, int D, int32_t *status,
+                               mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(disp_left && disp_right && status, MCCNN_E_INVALID, "mccnn_lr_status: null pointer");
+    MCCNN_REQUIRE(D > 0 && H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_lr_status: non-positive size");
+    hipLaunchKernelGGL(lr_status_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, (hipStream_t)stream, disp_left,
+                       disp_right, H, W, D, status);
+    return check_launch("mccnn_lr_status");
+}
+
+extern "C" int mccnn_interpolate(const float *disp_left, const int32_t *status, int H, int W, float *out,
+                                 mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(disp_left && status && out, MCCNN_E_INVALID, "mccnn_interpolate: null pointer");
+    MCCNN_REQUIRE(H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_interpolate: non-positive size");
+    MCCNN_REQUIRE(disp_left != out, MCCNN_E_INVALID, "mccnn_interpolate: out must not alias the input map");
+    hipLaunchKernelGGL(interpolate_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, (hipStream_t)stream, disp_left, status,
+                       H, W, out);
+    return check_launch("mccnn_interpolate");
+}
+
+extern "C" int mccnn_subpixel(const float *disp, const float *vol_dhw, int D, int H, int W, float *out,
+                              mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(disp && vol_dhw && out, MCCNN_E_INVALID, "mccnn_subpixel: null pointer");
+    MCCNN_REQUIRE(D > 0 && H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_subpixel: non-positive size");
+    const long N = (long)H * W;
+    hipLaunchKernelGGL(subpixel_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, disp, vol_dhw, D, N,
+                       out);
+    return check_launch("mccnn_subpixel");
+}
+
+extern "C" int mccnn_median(const float *disp, int H, int W, int fh, int fw, float *out, mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(disp && out, MCCNN_E_INVALID, "mccnn_median: null pointer");
+    MCCNN_REQUIRE(H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_median: non-positive size");
+    MCCNN_REQUIRE(disp != out, MCCNN_E_INVALID, "mccnn_median: out must not alias the input map");
+    MCCNN_REQUIRE(fh >= 1 && fw >= 1 && (fh & 1) && (fw & 1) && fh * fw <= MAXWIN, MCCNN_E_UNSUPPORTED,
+                  "mccnn_median: window %dx%d must be odd x odd with at most %d taps", fh, fw, MAXWIN);
+    hipLaunchKernelGGL(median_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, (hipStream_t)stream, disp, H, W, fh, fw,
+                       out);
+    return check_launch("mccnn_median");
+}
+
+extern "C" int mccnn_bilateral(const float *image, const float *disp, int H, int W, int fh, int fw, const float *table,
+                               float thr, float *out, mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(image && disp && table && out, MCCNN_E_INVALID, "mccnn_bilateral: null pointer");
+    MCCNN_REQUIRE(H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_bilateral: non-positive size");
+    MCCNN_REQUIRE(disp != out, MCCNN_E_INVALID, "mccnn_bilateral: out must not alias the input map");
+    MCCNN_REQUIRE(fh >= 1 && fw >= 1 && (fh & 1) && (fw & 1) && fh * fw <= MAXWIN, MCCNN_E_UNSUPPORTED,
+                  "mccnn_bilateral: window %dx%d must be odd x odd with at most %d taps", fh, fw, MAXWIN);
+    hipLaunchKernelGGL(bilateral_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, (hipStream_t)stream, image, disp, H, W,
+                       fh, fw, table, thr, out);
+    return check_launch("mccnn_bilateral");
+}
+
+extern "C" int mccnn_l2norm_chw_to_hwc(const float *chw, float *hwc, int C, int H, int W, mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(chw && hwc, MCCNN_E_INVALID, "mccnn_l2norm_chw_to_hwc: null pointer");
+    MCCNN_REQUIRE(H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_l2norm_chw_to_hwc: non-positive size");
+    MCCNN_REQUIRE(C == 64, MCCNN_E_UNSUPPORTED, "mccnn_l2norm_chw_to_hwc: C=%d, built for 64 feature maps", C);
+    const long N = (long)H * W;
+    hipLaunchKernelGGL((l2norm_chw_to_hwc_kernel<64>), dim3(cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, chw, hwc,
+                       N);
+    return check_launch("mccnn_l2norm_chw_to_hwc");
+}

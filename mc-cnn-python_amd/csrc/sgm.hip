@@ -1,0 +1,353 @@
+// a6 semi_global_matching (/root/reference/src/process_functional.py:476-568) on gfx950, plus the DHW <-> HWD
+// layout changes around it.
+//
+// Recurrence along r = (rh, rw), one scanline per wavefront, disparities on lanes:
+//     m      = min_k V[k, p-r]
+//     V[d,p] = (V[d,p] + min(V[d,p-r], V[d-1,p-r]+P1, V[d+1,p-r]+P1, m+P2)) - m          (pf:547-566)
+// with (P1,P2)(d,p) in {P, P/Q1, P/Q2} chosen by two threshold tests on image differences (pf:509-541).
+// float32 add / min / sub only, never fused: bit-exact against the reference.
+//
+// Why the pixel-major "HWD" layout: the recurrence consumes, at each step, the whole disparity vector of ONE
+// pixel.  In DHW those D floats are H*W*4 bytes apart; in HWD they are one contiguous run (1 KiB at D = 256), so a
+// wave issues one global_load_dwordx4 per lane per step (4 disparities per lane), both for horizontal (row) and
+// vertical (column) scanlines, and can keep PF steps in flight in registers - no LDS, no barriers.  The four
+// passes of SGM_average compose in place on the HWD copy; mccnn_dhw_to_hwd / mccnn_hwd_to_dhw convert once.
+//
+// Penalty classes without P1/P2/D2 volumes (the reference allocates three [D,H,W] temporaries, pf:504-507):
+//   a(p)   = |I_self(p)  - I_self(p-r)|          >= thr   one byte per pixel   ("A plane", from the volume's image)
+//   b(d,p) = |I_other(h,x) - I_other(h-rh,x-rw)| >= thr   x = w-d (left volume) or w+d (right volume); 0 where
+//            the reference skips (pf:517-518, 530-531)  -> one byte per pixel of the OTHER image ("B plane"),
+//            looked up at column w -/+ d.  Planes are padded by >= D columns of the "skipped" value on both sides
+//            so the lookup needs no bounds test.  class = a + b: 0 -> P, 1 -> P/Q1, 2 -> P/Q2.
+#include "common.h"
+
+namespace mccnn {
+
+// ---- flag planes ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sgm_flags_kernel(const float *__restrict__ img, int H, int W, int rh, int rw,
+                                                        float thr, int pitch, int pad, uint8_t *__restrict__ plane)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // padded column
+    const int h = blockIdx.y;
+    if (i >= pitch) return;
+    const int x = i - pad;
+    float diff = 0.f;  // D2 stays 0 where the reference `continue`s (pf:507)
+    const int xp = x - rw, hp = h - rh;
+    if (x >= 0 && x < W && xp >= 0 && xp < W && hp >= 0 && hp < H) {
+        const float t = img[(size_t)h * W + x] - img[(size_t)hp * W + xp];
+        const float sq = t * t;
+        diff = sqrtf(sq);  // np.linalg.norm of a 1-vector (pf:512,520)
+    }
+    plane[(size_t)h * pitch + i] = diff >= thr ? 1 : 0;
+}
+
+// ---- wave helpers ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_mov(float old, float src)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, 0xf,
+                                                      false));
+}
+
+// minimum over the 64 lanes, returned wave-uniform
+__device__ __forceinline__ float wave_min(float x)
+{
+    x = fminf(x, dpp_mov<0xB1>(x, x));        // quad_perm [1,0,3,2]
+    x = fminf(x, dpp_mov<0x4E>(x, x));        // quad_perm [2,3,0,1]
+    x = fminf(x, dpp_mov<0x141>(x, x));       // row_half_mirror
+    x = fminf(x, dpp_mov<0x140>(x, x));       // row_mirror: every lane of a 16-row holds the row minimum
+    x = fminf(x, dpp_mov<0x142, 0xA>(x, x));  // row_bcast:15 into rows 1 and 3
+    x = fminf(x, dpp_mov<0x143, 0xC>(x, x));  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the minimum
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+
+struct SgmJob {
+    float *vol;             // HWD volume, updated in place
+    const uint8_t *aplane;  // flags of the volume's own image
+    const uint8_t *bplane;  // flags of the other image
+    int dsign;              // -1: x = w - d (left volume), +1: x = w + d (right volume)
+};
+
+struct SgmParams {
+    SgmJob job[2];
+    int D, Dp, H, W, pitch, pad, rh, rw;
+    float p1[3], p2[3];  // indexed by class a+b: {P, P/Q1, P/Q2}
+};
+
+constexpr float kInf = __builtin_huge_valf();
+
+// NG = number of 256-disparity groups per lane (lane l of group g owns d = 256g + 4l .. +3), PF = steps in flight.
+template <int NG, int PF>
+__global__ __launch_bounds__(64) void sgm_pass_kernel(const SgmParams P)
+{
+    const SgmJob J = P.job[blockIdx.y];
+    const int lane = threadIdx.x;
+    const int line = blockIdx.x;
+    int h0, w0, nsteps;
+    if (P.rh == 0) { h0 = line; w0 = P.rw > 0 ? 0 : P.W - 1; nsteps = P.W - 1; }
+    else           { w0 = line; h0 = P.rh > 0 ? 0 : P.H - 1; nsteps = P.H - 1; }
+    const int D = P.D;
+    const int vecs = P.Dp >> 2;                          // float4 per pixel
+    const long pstep = (long)P.rh * P.W + P.rw;          // pixel index step along r
+    const long fstep = (long)P.rh * P.pitch + P.rw;      // flag-plane step along r
+    float4 *V = reinterpret_cast<float4 *>(J.vol);
+
+    bool act[NG];        // lane holds at least one real disparity in group g
+    int dlane[NG];       // first disparity of this lane in group g
+    long boff[NG];       // byte offset of this lane's 4 B-flags relative to the pixel's flag address
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        dlane[g] = g * 256 + lane * 4;
+        act[g] = dlane[g] < D;
+        boff[g] = J.dsign > 0 ? (long)dlane[g] : -(long)dlane[g] - 3;
+    }
+    const int shl = J.dsign > 0 ? 0 : 24;  // byte j of the packed flags sits at bit 8*j (dsign>0) or 8*(3-j)
+    const int sdir = J.dsign > 0 ? 8 : -8;
+
+    auto mask_tail = [&](float4 v, int g) {  // disparities >= D behave as +inf (never win a min, never stored)
+        const int d = dlane[g];
+        if (d + 0 >= D) v.x = kInf;
+        if (d + 1 >= D) v.y = kInf;
+        if (d + 2 >= D) v.z = kInf;
+        if (d + 3 >= D) v.w = kInf;
+        return v;
+    };
+
+    // step t touches pixel pix0 + t*pstep; step 0 is the untouched first line of the scan
+    const long pix0 = (long)h0 * P.W + w0;
+    const long flag0 = (long)h0 * P.pitch + P.pad + w0;
+
+    float4 prev[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        prev[g] = make_float4(kInf, kInf, kInf, kInf);
+        if (act[g]) prev[g] = mask_tail(V[pix0 * vecs + g * 64 + lane], g);
+    }
+    float m;
+    {
+        float lm = kInf;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) lm = fminf(lm, fminf(fminf(prev[g].x, prev[g].y), fminf(prev[g].z, prev[g].w)));
+        m = wave_min(lm);
+    }
+
+    float4 cbuf[PF][NG];
+    uint32_t fbuf[PF][NG];
+    uint32_t abuf[PF];
+
+    auto issue = [&](int slot, int t) {
+        const long pix = pix0 + (long)t * pstep;
+        const long fl = flag0 + (long)t * fstep;
+        abuf[slot] = J.aplane[fl];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            cbuf[slot][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+            fbuf[slot][g] = 0u;
+            if (act[g]) {
+                cbuf[slot][g] = V[pix * vecs + g * 64 + lane];
+                uint32_t u;
+                __builtin_memcpy(&u, J.bplane + fl + boff[g], 4);
+                fbuf[slot][g] = u;
+            }
+        }
+    };
+
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+        if (1 + k <= nsteps) issue(k, 1 + k);
+
+    for (int t0 = 1; t0 <= nsteps; t0 += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int t = t0 + k;
+            if (t > nsteps) break;
+            const long pix = pix0 + (long)t * pstep;
+            const int a = __builtin_amdgcn_readfirstlane((int)abuf[k]);
+            // class a+b: b = 0 -> index a, b = 1 -> index a+1
+            const float p1lo = a ? P.p1[1] : P.p1[0], p1hi = a ? P.p1[2] : P.p1[1];
+            const float p2lo = a ? P.p2[1] : P.p2[0], p2hi = a ? P.p2[2] : P.p2[1];
+            float4 nw[NG];
+            float lm = kInf;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                // every lane runs the arithmetic (the DPP lane shifts below must not sit in divergent code);
+                // lanes past the disparity range carry +inf and only their loads / stores are predicated
+                const float4 pv = prev[g];
+                // neighbours d-1 / d+1 across lanes; the ends of the disparity range see +inf (pf:552,566)
+                float below = dpp_mov<0x138>(kInf, pv.w);  // wave_shr:1 - lane l gets lane l-1
+                float above = dpp_mov<0x130>(kInf, pv.x);  // wave_shl:1 - lane l gets lane l+1
+                if (NG > 1) {
+                    if (g > 0 && lane == 0)
+                        below = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(prev[g > 0 ? g - 1 : 0].w), 63));
+                    if (g + 1 < NG && lane == 63)
+                        above = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(prev[g + 1 < NG ? g + 1 : g].x), 0));
+                }
+                const float4 c = mask_tail(cbuf[k][g], g);
+                const uint32_t fb = fbuf[k][g];
+                const bool b0 = (fb >> shl) & 1u, b1 = (fb >> (shl + sdir)) & 1u, b2 = (fb >> (shl + 2 * sdir)) & 1u,
+                           b3 = (fb >> (shl + 3 * sdir)) & 1u;
+                float4 o;
+                {
+                    const float q1 = b0 ? p1hi : p1lo, q2 = b0 ? p2hi : p2lo;
+                    const float best = fminf(fminf(pv.x, below + q1), fminf(pv.y + q1, m + q2));
+                    const float s = c.x + best;
+                    o.x = s - m;
+                }
+                {
+                    const float q1 = b1 ? p1hi : p1lo, q2 = b1 ? p2hi : p2lo;
+                    const float best = fminf(fminf(pv.y, pv.x + q1), fminf(pv.z + q1, m + q2));
+                    const float s = c.y + best;
+                    o.y = s - m;
+                }
+                {
+                    const float q1 = b2 ? p1hi : p1lo, q2 = b2 ? p2hi : p2lo;
+                    const float best = fminf(fminf(pv.z, pv.y + q1), fminf(pv.w + q1, m + q2));
+                    const float s = c.z + best;
+                    o.z = s - m;
+                }
+                {
+                    const float q1 = b3 ? p1hi : p1lo, q2 = b3 ? p2hi : p2lo;
+                    const float best = fminf(fminf(pv.w, pv.z + q1), fminf(above + q1, m + q2));
+                    const float s = c.w + best;
+                    o.w = s - m;
+                }
+                nw[g] = o;
+                if (act[g]) V[pix * vecs + g * 64 + lane] = o;
+                lm = fminf(lm, fminf(fminf(o.x, o.y), fminf(o.z, o.w)));
+            }
+            if (t + PF <= nsteps) issue(k, t + PF);
+            m = wave_min(lm);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) prev[g] = nw[g];
+        }
+    }
+}
+
+// ---- DHW <-> HWD: a [D x N] <-> [N x Dp] matrix transpose through a padded 64x64 LDS tile ------------------------
+__global__ __launch_bounds__(256) void dhw_to_hwd_kernel(const float *__restrict__ dhw, float *__restrict__ hwd, int D,
+                                                         long N, int Dp)
+{
+    __shared__ float tile[64][65];
+    const long n0 = (long)blockIdx.x * 64;
+    const int d0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {  // read rows of 64 pixels of plane d0 + r
+        const int d = d0 + r;
+        const long n = n0 + tx;
+        tile[r][tx] = (d < D && n < N) ? dhw[(size_t)d * N + n] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {  // write rows of 64 disparities of pixel n0 + r
+        const long n = n0 + r;
+        const int d = d0 + tx;
+        if (n < N && d < Dp) hwd[(size_t)n * Dp + d] = tile[tx][r];
+    }
+}
+
+__global__ __launch_bounds__(256) void hwd_to_dhw_kernel(const float *__restrict__ hwd, float *__restrict__ dhw, int D,
+                                                         long N, int Dp)
+{
+    __shared__ float tile[64][65];
+    const long n0 = (long)blockIdx.x * 64;
+    const int d0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const long n = n0 + r;
+        const int d = d0 + tx;
+        tile[r][tx] = (n < N && d < D) ? hwd[(size_t)n * Dp + d] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int d = d0 + r;
+        const long n = n0 + tx;
+        if (d < D && n < N) dhw[(size_t)d * N + n] = tile[tx][r];
+    }
+}
+
+static inline int flag_pad(int D) { return (D + 3 + 15) & ~15; }  // >= D+3: the packed 4-byte read may start 3 early
+
+}  // namespace mccnn
+
+extern "C" int mccnn_hwd_pitch(int D) { return (D + 3) & ~3; }
+
+extern "C" int mccnn_dhw_to_hwd(const float *dhw, float *hwd, int D, int H, int W, mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(dhw && hwd, MCCNN_E_INVALID, "mccnn_dhw_to_hwd: null pointer");
+    MCCNN_REQUIRE(D > 0 && H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_dhw_to_hwd: non-positive size");
+    const long N = (long)H * W;
+    const int Dp = mccnn_hwd_pitch(D);
+    hipLaunchKernelGGL(dhw_to_hwd_kernel, dim3(cdiv(N, 64), cdiv(Dp, 64)), dim3(256), 0, (hipStream_t)stream, dhw, hwd,
+                       D, N, Dp);
+    return check_launch("mccnn_dhw_to_hwd");
+}
+
+extern "C" int mccnn_hwd_to_dhw(const float *hwd, float *dhw, int D, int H, int W, mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(dhw && hwd, MCCNN_E_INVALID, "mccnn_hwd_to_dhw: null pointer");
+    MCCNN_REQUIRE(D > 0 && H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_hwd_to_dhw: non-positive size");
+    const long N = (long)H * W;
+    const int Dp = mccnn_hwd_pitch(D);
+    hipLaunchKernelGGL(hwd_to_dhw_kernel, dim3(cdiv(N, 64), cdiv(D, 64)), dim3(256), 0, (hipStream_t)stream, hwd, dhw,
+                       D, N, Dp);
+    return check_launch("mccnn_hwd_to_dhw");
+}
+
+extern "C" size_t mccnn_sgm_scratch_bytes(int H, int W, int D)
+{
+    if (H <= 0 || W <= 0 || D <= 0) return 0;
+    const size_t pitch = (size_t)W + 2 * (size_t)mccnn::flag_pad(D);
+    return 2 * (size_t)H * pitch + 256;  // one flag plane per image
+}
+
+extern "C" int mccnn_sgm_pass(const float *image_left, const float *image_right, float *const *vol_hwd, const int *side,
+                              int n_jobs, int D, int H, int W, int rh, int rw, float p1, float p2, float q1, float q2,
+                              float thr, void *scratch, size_t scratch_bytes, mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(image_left && image_right && vol_hwd && side && scratch, MCCNN_E_INVALID,
+                  "mccnn_sgm_pass: null pointer");
+    MCCNN_REQUIRE(n_jobs == 1 || n_jobs == 2, MCCNN_E_INVALID, "mccnn_sgm_pass: n_jobs=%d must be 1 or 2", n_jobs);
+    MCCNN_REQUIRE(H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_sgm_pass: non-positive size");
+    MCCNN_REQUIRE(D >= 2 && D <= 512, MCCNN_E_UNSUPPORTED,
+                  "mccnn_sgm_pass: D=%d outside [2,512] (the reference itself needs D >= 2, pf:550)", D);
+    MCCNN_REQUIRE((rh == 0 && (rw == 1 || rw == -1)) || (rw == 0 && (rh == 1 || rh == -1)), MCCNN_E_INVALID,
+                  "mccnn_sgm_pass: r=(%d,%d) is not an axis-aligned unit step (pf:484)", rh, rw);
+    MCCNN_REQUIRE(scratch_bytes >= mccnn_sgm_scratch_bytes(H, W, D), MCCNN_E_SCRATCH,
+                  "mccnn_sgm_pass: scratch %zu < %zu bytes", scratch_bytes, mccnn_sgm_scratch_bytes(H, W, D));
+    hipStream_t s = (hipStream_t)stream;
+    const int pad = flag_pad(D);
+    const int pitch = W + 2 * pad;
+    uint8_t *plane_l = reinterpret_cast<uint8_t *>(scratch);
+    uint8_t *plane_r = plane_l + (((size_t)H * pitch + 127) & ~(size_t)127);
+    const dim3 fgrid(cdiv(pitch, 256), H), fblock(256);
+    hipLaunchKernelGGL(sgm_flags_kernel, fgrid, fblock, 0, s, image_left, H, W, rh, rw, thr, pitch, pad, plane_l);
+    hipLaunchKernelGGL(sgm_flags_kernel, fgrid, fblock, 0, s, image_right, H, W, rh, rw, thr, pitch, pad, plane_r);
+    int rc = check_launch("mccnn_sgm_pass(flags)");
+    if (rc) return rc;
+
+    SgmParams P;
+    for (int j = 0; j < 2; ++j) {
+        const int jj = j < n_jobs ? j : 0;
+        MCCNN_REQUIRE(vol_hwd[jj] != nullptr, MCCNN_E_INVALID, "mccnn_sgm_pass: null volume");
+        MCCNN_REQUIRE(side[jj] == MCCNN_SIDE_LEFT || side[jj] == MCCNN_SIDE_RIGHT, MCCNN_E_INVALID,
+                      "mccnn_sgm_pass: side must be MCCNN_SIDE_LEFT or MCCNN_SIDE_RIGHT");
+        P.job[j].vol = vol_hwd[jj];
+        const bool left = side[jj] == MCCNN_SIDE_LEFT;
+        P.job[j].aplane = left ? plane_l : plane_r;
+        P.job[j].bplane = left ? plane_r : plane_l;
+        P.job[j].dsign = left ? -1 : +1;
+    }
+    P.D = D; P.Dp = mccnn_hwd_pitch(D); P.H = H; P.W = W; P.pitch = pitch; P.pad = pad; P.rh = rh; P.rw = rw;
+    P.p1[0] = p1; P.p1[1] = p1 / q1; P.p1[2] = p1 / q2;  // pf:538-541 (float32 divisions)
+    P.p2[0] = p2; P.p2[1] = p2 / q1; P.p2[2] = p2 / q2;
+    const int nlines = rh == 0 ? H : W;
+    if ((rh == 0 ? W : H) < 2) return 0;  // nothing to scan
+    const dim3 grid(nlines, n_jobs), block(64);
+    if (D <= 256)
+        hipLaunchKernelGGL((sgm_pass_kernel<1, 8>), grid, block, 0, s, P);
+    else
+        hipLaunchKernelGGL((sgm_pass_kernel<2, 4>), grid, block, 0, s, P);
+    return check_launch("mccnn_sgm_pass");
+}

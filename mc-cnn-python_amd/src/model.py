@@ -1,0 +1,145 @@
+"""Feature head of the "fast" MC-CNN - drop-in for /root/reference/src/model.py (NET, :9-65; conv, :90-125).
+
+Same constructor arguments and attributes (`.X`, `.conv1 ... .convN`, `.features`); the TensorFlow graph is
+replaced by eager PyTorch-ROCm convolutions (MIOpen), which is where north_star keeps the small conv stack.
+Topology (model.py:51-64): num_conv_layers x (3x3 VALID conv, 64 maps), ReLU after all but the last, then
+channel-wise L2 normalisation x * rsqrt(max(sum x^2, 1e-12)).  Fully convolutional: 11x11 patches give
+[B,1,1,64]; an image zero-padded once by (patch-1)/2 (process_functional.py:20-25) gives [1,H,W,64].
+
+Differences a maintainer should know:
+  * `NET(x, ...)` evaluates immediately when `x` is a tensor / array (there is no session); `NET(None, ...)` builds
+    the weights only, and `net(x)` / `net.features_hwc(image)` evaluate later.
+  * weights come from `restore(checkpoint)` - a TF bundle prefix (the reference's --resume) or an .npz.
+  * whole-image features use the HIP epilogue mccnn_l2norm_chw_to_hwc (NCHW conv output -> NHWC unit vectors).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import tf_checkpoint
+
+
+class NET(object):
+
+    def __init__(self, x=None, weights_path='DEFAULT',
+                 input_patch_size=11, num_conv_layers=5, num_conv_feature_maps=64,
+                 conv_kernel_size=3, batch_size=128, device=None, seed=0):
+        self.X = x
+        self.batch_size = batch_size
+        self.input_patch_size = input_patch_size
+        self.num_conv_layers = num_conv_layers
+        self.num_conv_feature_maps = num_conv_feature_maps
+        self.conv_kernel_size = conv_kernel_size
+        self.WEIGHTS_PATH = 'pretrain.npy' if weights_path == 'DEFAULT' else weights_path
+        if device is None:
+            if torch.is_tensor(x):
+                device = x.device
+            else:
+                device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+        self.device = torch.device(device)
+        self._init_variables(seed)
+        if x is not None:
+            self.create()
+
+    # -- variables: conv{k}/weights [k,k,Cin,Cout] (HWIO) and conv{k}/biases [Cout], model.py:98-101 -----------------
+    def _init_variables(self, seed):
+        g = torch.Generator().manual_seed(seed)
+        k, nf = self.conv_kernel_size, self.num_conv_feature_maps
+        self.weights = []  # torch layout [Cout, Cin, k, k]
+        self.biases = []
+        cin = 1
+        for _ in range(self.num_conv_layers):
+            # tf.get_variable's default initializer is glorot_uniform
+            limit = math.sqrt(6.0 / (k * k * cin + k * k * nf))
+            w = (torch.rand((nf, cin, k, k), generator=g) * 2 - 1) * limit
+            blim = math.sqrt(6.0 / (nf + nf))
+            b = (torch.rand((nf,), generator=g) * 2 - 1) * blim
+            self.weights.append(w.to(self.device))
+            self.biases.append(b.to(self.device))
+            cin = nf
+
+    def set_layers(self, layers):
+        """layers: list of (w_hwio float32 [k,k,Cin,Cout], bias [Cout]) as stored by TensorFlow."""
+        assert len(layers) == self.num_conv_layers, "checkpoint has %d conv layers, NET was built with %d" % (
+            len(layers), self.num_conv_layers)
+        self.weights = [torch.from_numpy(np.ascontiguousarray(np.transpose(w, (3, 2, 0, 1)))).to(self.device)
+                        for w, _ in layers]
+        self.biases = [torch.from_numpy(np.ascontiguousarray(b)).to(self.device) for _, b in layers]
+        return self
+
+    def get_layers(self):
+        return [(np.ascontiguousarray(w.permute(2, 3, 1, 0).cpu().numpy()), b.cpu().numpy())
+                for w, b in zip(self.weights, self.biases)]
+
+    def restore(self, checkpoint):
+        """The reference's `saver.restore(sess, checkpoint)` (process_functional.py:43)."""
+        return self.set_layers(tf_checkpoint.load_fast_net_weights(checkpoint))
+
+    # -- the two unused .npy helpers of the reference (model.py:67-85), kept for API completeness ---------------------
+    def load_initial_weights(self, session=None):
+        weights_dict = np.load(self.WEIGHTS_PATH, encoding='bytes', allow_pickle=True).item()
+        layers = self.get_layers()
+        for name, value in weights_dict.items():
+            name = name.decode() if isinstance(name, bytes) else name
+            scope, var = name.split(":")[0].split("/")
+            idx = int(scope.replace("conv", "")) - 1
+            w, b = layers[idx]
+            layers[idx] = (np.asarray(value, np.float32), b) if var == "weights" else (w, np.asarray(value, np.float32))
+        self.set_layers(layers)
+
+    def save_weights(self, session=None, file_name='pretrain.npy'):
+        weights_dict = {}
+        for k, (w, b) in enumerate(self.get_layers(), start=1):
+            weights_dict["conv%d/weights:0" % k] = w
+            weights_dict["conv%d/biases:0" % k] = b
+        np.save(file_name, weights_dict)
+
+    # -- forward ------------------------------------------------------------------------------------------------------
+    def _convs_nchw(self, x):
+        """x: [B,1,h,w] -> list of conv outputs, NCHW (ReLU on all but the last, model.py:51-61)."""
+        outs = []
+        nl = self.num_conv_layers
+        for k in range(nl):
+            x = F.conv2d(x, self.weights[k], self.biases[k])
+            if k < nl - 1:
+                x = F.relu(x)
+            outs.append(x)
+        return outs
+
+    @staticmethod
+    def _l2_normalize_last(x):
+        # tf.nn.l2_normalize(x, dim=-1): x * rsqrt(max(sum(x^2), 1e-12))  (model.py:64)
+        s = torch.clamp((x * x).sum(dim=-1, keepdim=True), min=1e-12)
+        return x * torch.rsqrt(s)
+
+    def create(self):
+        """Evaluates the graph on self.X (NHWC [B,h,w,1]) and exposes conv1..convN and features (NHWC)."""
+        self(self.X)
+
+    def __call__(self, x):
+        x = torch.as_tensor(x, dtype=torch.float32).to(self.device)
+        assert x.dim() == 4 and x.shape[-1] == 1, "NET expects NHWC input with one channel (model.py:36-40)"
+        self.X = x
+        outs = self._convs_nchw(x.permute(0, 3, 1, 2).contiguous())
+        for k, o in enumerate(outs, start=1):
+            setattr(self, "conv%d" % k, o.permute(0, 2, 3, 1))
+        self.features = self._l2_normalize_last(outs[-1].permute(0, 2, 3, 1))
+        return self.features
+
+    def features_hwc(self, image_hw):
+        """Whole-image path of compute_features (process_functional.py:20-34, 62-67) on the GPU.
+        image_hw: standardised float32 device tensor [H,W] -> [H,W,64] unit feature vectors."""
+        import stereo_device
+        pad = (self.input_patch_size - 1) // 2
+        assert pad == self.num_conv_layers * (self.conv_kernel_size - 1) // 2, \
+            "patch size must equal the receptive field so that features keep the image size"
+        x = F.pad(image_hw[None, None], (pad, pad, pad, pad))  # zero-pad ONCE; every conv is VALID
+        out = self._convs_nchw(x)[-1][0].contiguous()          # [64,H,W]
+        return stereo_device.l2norm_chw_to_hwc(out)
+
+
+if __name__ == "__main__":
+    net = NET(torch.zeros([128, 11, 11, 1]))
+    print(net.features.shape)

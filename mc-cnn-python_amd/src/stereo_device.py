@@ -1,0 +1,355 @@
+"""Device-resident stages of the hot path: thin, allocation-aware wrappers over the C ABI (include/mccnn.h).
+
+Everything here takes and returns torch device tensors; nothing touches host memory and nothing is computed by
+PyTorch except the 5-layer conv stack (model.NET).  The NumPy-facing drop-in lives in process_functional.py and the
+whole-pair driver (the timed region of the reference's match.py:129-179) is StereoMatcher.match below.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+import _hipabi as hip
+
+
+def _f32(x):
+    """The float32 rounding NumPy 2 applies when a Python scalar meets a float32 array."""
+    return float(np.float32(x))
+
+
+class StageTimer(object):
+    """Optional per-stage HIP-event timing on the stream the kernels run on (bench.py turns it on)."""
+
+    def __init__(self, enabled=False):
+        self.enabled = enabled
+        self.records = []  # (name, start_event, end_event)
+        self._open = None
+
+    def start(self, name):
+        if not self.enabled:
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self._open = (name, ev)
+
+    def stop(self):
+        if not self.enabled or self._open is None:
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.records.append((self._open[0], self._open[1], ev))
+        self._open = None
+
+    def summary_ms(self):
+        """{name: [ms, ...]} - call after torch.cuda.synchronize()."""
+        out = {}
+        for name, a, b in self.records:
+            out.setdefault(name, []).append(a.elapsed_time(b))
+        return out
+
+
+_NO_TIMER = StageTimer(False)
+
+
+# ---- a1 ----------------------------------------------------------------------------------------------------------
+def l2norm_chw_to_hwc(chw):
+    """[C,H,W] conv output -> [H,W,C] unit feature vectors (model.py:64)."""
+    C, H, W = chw.shape
+    out = torch.empty((H, W, C), dtype=torch.float32, device=chw.device)
+    hip.check(hip.load().mccnn_l2norm_chw_to_hwc(hip.ptr(chw), hip.ptr(out), C, H, W, hip.stream()),
+              "mccnn_l2norm_chw_to_hwc")
+    return out
+
+
+# ---- a2 ----------------------------------------------------------------------------------------------------------
+def cost_volume(fl, fr, ndisp, mode=hip.MCCNN_CV_EXACT, out=None):
+    H, W, C = fl.shape
+    if out is None:
+        lcv = torch.empty((ndisp, H, W), dtype=torch.float32, device=fl.device)
+        rcv = torch.empty((ndisp, H, W), dtype=torch.float32, device=fl.device)
+    else:
+        lcv, rcv = out
+    hip.check(hip.load().mccnn_cost_volume(hip.ptr(fl), hip.ptr(fr), H, W, C, int(ndisp), hip.ptr(lcv), hip.ptr(rcv),
+                                           int(mode), hip.stream()), "mccnn_cost_volume")
+    return lcv, rcv
+
+
+# ---- a3 ----------------------------------------------------------------------------------------------------------
+def cross_arms(image, intensity_threshold, distance_threshold):
+    """image [H,W] -> (arms uint8 [H,W,4] = up,down,left,right; count int32 [H,W])."""
+    H, W = image.shape
+    arms = torch.empty((H, W, 4), dtype=torch.uint8, device=image.device)
+    count = torch.empty((H, W), dtype=torch.int32, device=image.device)
+    hip.check(hip.load().mccnn_cross_arms(hip.ptr(image), H, W, _f32(intensity_threshold), int(distance_threshold),
+                                          hip.ptr(arms), hip.ptr(count), hip.stream()), "mccnn_cross_arms")
+    return arms, count
+
+
+def cross_region_list(arms, distance_threshold):
+    H, W, _ = arms.shape
+    L = int(distance_threshold)
+    region = torch.empty((H, W, (2 * L) ** 2, 2), dtype=torch.int32, device=arms.device)
+    hip.check(hip.load().mccnn_cross_region_list(hip.ptr(arms), H, W, L, hip.ptr(region), hip.stream()),
+              "mccnn_cross_region_list")
+    return region
+
+
+# ---- a4 ----------------------------------------------------------------------------------------------------------
+def cbca(vol, tmp, arms, count, iterations, distance_threshold, order=hip.MCCNN_CBCA_SEPARABLE):
+    """`iterations` rounds of cross-based averaging.  Ping-pongs between `vol` and `tmp` (same shape);
+    returns (result, spare) - the input buffer is clobbered when iterations >= 2, the reference's is not, so
+    callers that need the input keep their own copy."""
+    D, H, W = vol.shape
+    lib = hip.load()
+    src, dst = vol, tmp
+    for _ in range(int(iterations)):
+        hip.check(lib.mccnn_cbca_iter(hip.ptr(src), hip.ptr(dst), hip.ptr(arms), hip.ptr(count), D, H, W,
+                                      int(distance_threshold), int(order), hip.stream()), "mccnn_cbca_iter")
+        src, dst = dst, src
+    return src, dst
+
+
+# ---- a5 / a6 -------------------------------------------------------------------------------------------------------
+def hwd_pitch(D):
+    return hip.load().mccnn_hwd_pitch(int(D))
+
+
+def dhw_to_hwd(dhw, hwd=None):
+    D, H, W = dhw.shape
+    if hwd is None:
+        hwd = torch.empty((H, W, hwd_pitch(D)), dtype=torch.float32, device=dhw.device)
+    hip.check(hip.load().mccnn_dhw_to_hwd(hip.ptr(dhw), hip.ptr(hwd), D, H, W, hip.stream()), "mccnn_dhw_to_hwd")
+    return hwd
+
+
+def hwd_to_dhw(hwd, D, dhw=None):
+    H, W, _ = hwd.shape
+    if dhw is None:
+        dhw = torch.empty((D, H, W), dtype=torch.float32, device=hwd.device)
+    hip.check(hip.load().mccnn_hwd_to_dhw(hip.ptr(hwd), hip.ptr(dhw), int(D), H, W, hip.stream()), "mccnn_hwd_to_dhw")
+    return dhw
+
+
+def sgm_scratch(H, W, D, device):
+    n = hip.load().mccnn_sgm_scratch_bytes(H, W, int(D))
+    return torch.empty((n,), dtype=torch.uint8, device=device)
+
+
+def sgm_pass_hwd(image_left, image_right, vols_hwd, sides, D, r, p1, p2, q1, q2, thr, scratch):
+    """One direction, in place on 1 or 2 HWD volumes.  p1..thr are already float32-rounded Python floats."""
+    H, W = image_left.shape
+    n = len(vols_hwd)
+    vol_arr = (ctypes.c_void_p * 2)(*([v.data_ptr() for v in vols_hwd] + [None] * (2 - n)))
+    side_arr = (ctypes.c_int * 2)(*(list(sides) + [0] * (2 - n)))
+    hip.check(hip.load().mccnn_sgm_pass(hip.ptr(image_left), hip.ptr(image_right), vol_arr, side_arr, n, int(D), H, W,
+                                        int(r[0]), int(r[1]), p1, p2, q1, q2, thr, hip.ptr(scratch),
+                                        scratch.numel(), hip.stream()), "mccnn_sgm_pass")
+
+
+SGM_DIRECTIONS = ((0, 1), (0, -1), (-1, 0), (1, 0))  # right, left, up, bottom (pf:194-208)
+
+
+def sgm_average_hwd(image_left, image_right, vols_hwd, sides, D, sgm_P1, sgm_P2, sgm_Q1, sgm_Q2, sgm_D, sgm_V,
+                    scratch, timer=_NO_TIMER):
+    """SGM_average (pf:187-235) on HWD volumes: the four passes compose in place (the reference aliases one array,
+    pf:544,568) and its '(a+b+c+d)/4.' of four aliases of that array is the identity in binary floating point
+    (oracle/mccnn_oracle.c evaluates it literally; the parity tests pin the equality)."""
+    p1h = _f32(sgm_P1)
+    p1v = _f32(sgm_P1 / sgm_V)  # Python double division, rounded once (pf:204)
+    p2, q1, q2, thr = _f32(sgm_P2), _f32(sgm_Q1), _f32(sgm_Q2), _f32(sgm_D)
+    for r in SGM_DIRECTIONS:
+        timer.start("sgm_pass")
+        sgm_pass_hwd(image_left, image_right, vols_hwd, sides, D, r, p1h if r[0] == 0 else p1v, p2, q1, q2, thr,
+                     scratch)
+        timer.stop()
+
+
+# ---- a7 .. a11 -----------------------------------------------------------------------------------------------------
+def wta(vol):
+    D, H, W = vol.shape
+    disp = torch.empty((H, W), dtype=torch.float32, device=vol.device)
+    hip.check(hip.load().mccnn_wta(hip.ptr(vol), D, H, W, hip.ptr(disp), hip.stream()), "mccnn_wta")
+    return disp
+
+
+def lr_status(dl, dr, ndisp):
+    H, W = dl.shape
+    st = torch.empty((H, W), dtype=torch.int32, device=dl.device)
+    hip.check(hip.load().mccnn_lr_status(hip.ptr(dl), hip.ptr(dr), H, W, int(ndisp), hip.ptr(st), hip.stream()),
+              "mccnn_lr_status")
+    return st
+
+
+def interpolate(dl, status):
+    H, W = dl.shape
+    out = torch.empty_like(dl)
+    hip.check(hip.load().mccnn_interpolate(hip.ptr(dl), hip.ptr(status), H, W, hip.ptr(out), hip.stream()),
+              "mccnn_interpolate")
+    return out
+
+
+def subpixel(dl, vol):
+    D, H, W = vol.shape
+    out = torch.empty_like(dl)
+    hip.check(hip.load().mccnn_subpixel(hip.ptr(dl), hip.ptr(vol), D, H, W, hip.ptr(out), hip.stream()),
+              "mccnn_subpixel")
+    return out
+
+
+def median(dl, fh, fw):
+    H, W = dl.shape
+    out = torch.empty_like(dl)
+    hip.check(hip.load().mccnn_median(hip.ptr(dl), H, W, int(fh), int(fw), hip.ptr(out), hip.stream()),
+              "mccnn_median")
+    return out
+
+
+def bilateral_table(filter_height, filter_width, mean, std_dev):
+    """The reference's spatial kernel (pf:428-436, util.normal util.py:45-48): float64 evaluation, float32 storage."""
+    constant1 = 1. / (np.sqrt(2 * np.pi) * std_dev)
+    constant2 = -1. / (2 * std_dev * std_dev)
+    center_h = (filter_height - 1) // 2
+    center_w = (filter_width - 1) // 2
+    tab = np.zeros([filter_height, filter_width], dtype=np.float32)
+    for h in range(filter_height):
+        for w in range(filter_width):
+            x = np.sqrt((h - center_h) ** 2 + (w - center_w) ** 2)
+            tab[h, w] = constant1 * np.exp(constant2 * ((x - mean) ** 2))
+    return tab
+
+
+def bilateral(image, dl, fh, fw, mean, std_dev, blur_threshold):
+    H, W = dl.shape
+    tab = torch.from_numpy(bilateral_table(int(fh), int(fw), mean, std_dev)).to(dl.device)
+    out = torch.empty_like(dl)
+    hip.check(hip.load().mccnn_bilateral(hip.ptr(image), hip.ptr(dl), H, W, int(fh), int(fw), hip.ptr(tab),
+                                         _f32(blur_threshold), hip.ptr(out), hip.stream()), "mccnn_bilateral")
+    return out
+
+
+# ---- whole pair ----------------------------------------------------------------------------------------------------
+DEFAULT_HP = dict(cbca_intensity=0.02, cbca_distance=14, cbca_num_iterations1=2, cbca_num_iterations2=16,
+                  sgm_P1=2.3, sgm_P2=55.9, sgm_Q1=4, sgm_Q2=8, sgm_D=0.08, sgm_V=1.5, blur_sigma=6,
+                  blur_threshold=2)  # match.py:32-43
+
+
+class StereoMatcher(object):
+    """The timed region of match.py:129-179 for one stereo pair, resident on one GPU.
+
+    net: model.NET with weights loaded (kept resident; the reference re-restores per pair, pf:43).
+    cv_mode / cbca_order select the bit-exact or the fast variant of those two stages.
+    """
+
+    def __init__(self, net, hp=None, cv_mode=hip.MCCNN_CV_EXACT, cbca_order=hip.MCCNN_CBCA_SEPARABLE):
+        self.device = hip.require_device()
+        self.net = net
+        self.hp = dict(DEFAULT_HP)
+        if hp:
+            self.hp.update(hp)
+        self.cv_mode = cv_mode
+        self.cbca_order = cbca_order
+        self._ws = {}
+
+    def workspace(self, H, W, D):
+        key = (H, W, D)
+        ws = self._ws.get(key)
+        if ws is None:
+            dp = hwd_pitch(D)
+            n = H * W * dp
+            dev = self.device
+            ws = dict(
+                lcv=torch.empty((D, H, W), dtype=torch.float32, device=dev),
+                rcv=torch.empty((D, H, W), dtype=torch.float32, device=dev),
+                t1=torch.empty((n,), dtype=torch.float32, device=dev),
+                t2=torch.empty((n,), dtype=torch.float32, device=dev),
+                scratch=sgm_scratch(H, W, D, dev),
+            )
+            self._ws = {key: ws}  # one shape resident at a time
+        return ws
+
+    def match(self, left_image, right_image, ndisp, timer=_NO_TIMER, keep=None):
+        """left/right: standardised float32 device tensors [H,W] (or [H,W,1]).  Returns the final left disparity
+        map [H,W] on the device.  `keep`, if a dict, receives intermediate device tensors (tests)."""
+        hp = self.hp
+        L = left_image.reshape(left_image.shape[0], left_image.shape[1]).contiguous()
+        R = right_image.reshape(right_image.shape[0], right_image.shape[1]).contiguous()
+        H, W = L.shape
+        D = int(ndisp)
+        ws = self.workspace(H, W, D)
+        dhw = (D, H, W)
+        hwd = (H, W, hwd_pitch(D))
+        nd, nh = D * H * W, H * W * hwd[2]
+
+        timer.start("features")
+        fl = self.net.features_hwc(L)
+        fr = self.net.features_hwc(R)
+        timer.stop()
+
+        timer.start("cost_volume")
+        lcv, rcv = cost_volume(fl, fr, D, self.cv_mode, out=(ws["lcv"], ws["rcv"]))
+        timer.stop()
+        del fl, fr
+        if keep is not None:
+            keep["cv"] = (lcv.clone(), rcv.clone())
+
+        timer.start("cross_arms")
+        arms_l, cnt_l = cross_arms(L, hp["cbca_intensity"], hp["cbca_distance"])
+        arms_r, cnt_r = cross_arms(R, hp["cbca_intensity"], hp["cbca_distance"])
+        timer.stop()
+
+        t1d, t2d = ws["t1"][:nd].view(dhw), ws["t2"][:nd].view(dhw)
+        timer.start("cbca1")
+        lcv, t1d = cbca(lcv, t1d, arms_l, cnt_l, hp["cbca_num_iterations1"], hp["cbca_distance"], self.cbca_order)
+        rcv, t2d = cbca(rcv, t2d, arms_r, cnt_r, hp["cbca_num_iterations1"], hp["cbca_distance"], self.cbca_order)
+        timer.stop()
+        if keep is not None:
+            keep["cbca1"] = (lcv.clone(), rcv.clone())
+
+        # SGM on pixel-major copies; t1d/t2d are the spare buffers (possibly swapped with ws[lcv/rcv] by the ping-pong)
+        timer.start("dhw_to_hwd")
+        lh = dhw_to_hwd(lcv, self._as_hwd(t1d, ws, hwd, nh))
+        rh = dhw_to_hwd(rcv, self._as_hwd(t2d, ws, hwd, nh))
+        timer.stop()
+        sgm_average_hwd(L, R, [lh, rh], [hip.MCCNN_SIDE_LEFT, hip.MCCNN_SIDE_RIGHT], D, hp["sgm_P1"], hp["sgm_P2"],
+                        hp["sgm_Q1"], hp["sgm_Q2"], hp["sgm_D"], hp["sgm_V"], ws["scratch"], timer)
+        timer.start("hwd_to_dhw")
+        hwd_to_dhw(lh, D, lcv)
+        hwd_to_dhw(rh, D, rcv)
+        timer.stop()
+        if keep is not None:
+            keep["sgm"] = (lcv.clone(), rcv.clone())
+
+        timer.start("cbca2")
+        lcv, t1d = cbca(lcv, t1d, arms_l, cnt_l, hp["cbca_num_iterations2"], hp["cbca_distance"], self.cbca_order)
+        rcv, t2d = cbca(rcv, t2d, arms_r, cnt_r, hp["cbca_num_iterations2"], hp["cbca_distance"], self.cbca_order)
+        timer.stop()
+        if keep is not None:
+            keep["cbca2"] = (lcv.clone(), rcv.clone())
+
+        timer.start("wta")
+        dl = wta(lcv)
+        dr = wta(rcv)
+        timer.stop()
+        timer.start("post")
+        st = lr_status(dl, dr, D)
+        di = interpolate(dl, st)
+        ds = subpixel(di, lcv)
+        dm = median(ds, 5, 5)
+        db = bilateral(L, dm, 5, 5, 0, hp["blur_sigma"], hp["blur_threshold"])
+        timer.stop()
+        if keep is not None:
+            keep.update(wta=(dl, dr), status=st, interp=di, subpixel=ds, median=dm, bilateral=db)
+        return db
+
+    @staticmethod
+    def _as_hwd(spare_dhw, ws, hwd, nh):
+        """The spare ping-pong buffer viewed as an HWD volume (both live in the t1/t2 or lcv/rcv allocations; the
+        t buffers are sized for the HWD pitch, the cv buffers only when Dp == D)."""
+        base = spare_dhw.reshape(-1)
+        for name in ("t1", "t2"):
+            if base.data_ptr() == ws[name].data_ptr():
+                return ws[name][:nh].view(hwd)
+        if nh == base.numel():
+            return base.view(hwd)
+        return torch.empty(hwd, dtype=torch.float32, device=base.device)

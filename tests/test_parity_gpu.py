@@ -1,0 +1,386 @@
+"""GPU: the HIP path, called through the C ABI (libmccnn_hip.so via ctypes), against
+  (1) the committed golden vectors produced by the reference itself, and
+  (2) the CPU oracle on seeded inputs at sizes the oracle finishes in seconds.
+
+Tolerances:
+  bit-exact   cost volume (exact mode), arms/counts, CBCA (reference order), every SGM pass, WTA index, LR/interp,
+              sub-pixel, median, bilateral
+  <= 2e-6     cost volume on the matrix cores (fma-chain order instead of NumPy's pairwise order)
+  <= 1e-6/it  CBCA separable order (same set, different float32 association)
+  <= 1e-5     features vs the float64-accumulating restatement (TensorFlow parity itself is unpinned)
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_bits, bits_equal, hp_of
+
+pytestmark = pytest.mark.gpu
+
+DIRS = dict(right=(0, 1), left=(0, -1), up=(-1, 0), bottom=(1, 0))
+
+
+@pytest.fixture(scope="module")
+def pf():
+    import _hipabi
+    _hipabi.require_device()
+    import process_functional
+    return process_functional
+
+
+@pytest.fixture(scope="module")
+def sd():
+    import stereo_device
+    return stereo_device
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# (1) golden vectors
+# ---------------------------------------------------------------------------------------------------------------
+def test_golden_cost_volume_exact(pf, golden_cases):
+    pf.COST_VOLUME_MODE = "exact"
+    for name, g in golden_cases:
+        l, r = pf.compute_cost_volume(g["fl"], g["fr"], g["cv_l"].shape[0])
+        assert_bits(l, g["cv_l"], name + " cv_l")
+        assert_bits(r, g["cv_r"], name + " cv_r")
+
+
+def test_golden_cost_volume_mfma(pf, golden_cases):
+    pf.COST_VOLUME_MODE = "mfma"
+    try:
+        for name, g in golden_cases:
+            l, r = pf.compute_cost_volume(g["fl"], g["fr"], g["cv_l"].shape[0])
+            assert np.abs(l - g["cv_l"]).max() <= 2e-6, name
+            assert np.abs(r - g["cv_r"]).max() <= 2e-6, name
+    finally:
+        pf.COST_VOLUME_MODE = "exact"
+
+
+def test_golden_cross_region(pf, sd, golden_cases):
+    for name, g in golden_cases:
+        hp = hp_of(g)
+        for side in "lr":
+            img = dev(g["left" if side == "l" else "right"][:, :, 0])
+            arms, cnt = sd.cross_arms(img, hp["cbca_intensity"], int(hp["cbca_distance"]))
+            assert np.array_equal(arms.cpu().numpy(), g["arms_" + side]), name
+            assert np.array_equal(cnt.cpu().numpy(), g["region_num_" + side]), name
+        if "region_l_crop" in g:
+            reg, num = pf.compute_cross_region(g["left"], hp["cbca_intensity"], hp["cbca_distance"])
+            assert reg.dtype == np.int32 and reg.shape == (g["left"].shape[0], g["left"].shape[1], 784, 2)
+            assert np.array_equal(reg[:6, :8], g["region_l_crop"])
+            assert np.array_equal(num, g["region_num_l"])
+
+
+def test_golden_cbca_reference_order_bit_exact(pf, golden_cases):
+    pf.CBCA_ORDER = "reference"
+    try:
+        for name, g in golden_cases:
+            hp = hp_of(g)
+            tau, dist = hp["cbca_intensity"], hp["cbca_distance"]
+            cv_l = g["cv_l"].copy()
+            l, r = pf.cost_volume_aggregation(g["left"], g["right"], cv_l, g["cv_r"], tau, dist, 1)
+            assert_bits(l, g["cbca1it_l"], name)
+            assert_bits(r, g["cbca1it_r"], name)
+            assert_bits(cv_l, g["cv_l"], name + " (input untouched)")
+            l, r = pf.cost_volume_aggregation(g["left"], g["right"], g["cv_l"], g["cv_r"], tau, dist, hp["it1"])
+            assert_bits(l, g["cbca1_l"], name)
+            assert_bits(r, g["cbca1_r"], name)
+            l, r = pf.cost_volume_aggregation(g["left"], g["right"], g["sgm_l"], g["sgm_r"], tau, dist, hp["it2"])
+            assert_bits(l, g["cbca2_l"], name)
+            assert_bits(r, g["cbca2_r"], name)
+    finally:
+        pf.CBCA_ORDER = "separable"
+
+
+def test_golden_cbca_separable_tolerance(pf, golden_cases):
+    pf.CBCA_ORDER = "separable"
+    for name, g in golden_cases:
+        hp = hp_of(g)
+        tau, dist = hp["cbca_intensity"], hp["cbca_distance"]
+        l, r = pf.cost_volume_aggregation(g["left"], g["right"], g["cv_l"], g["cv_r"], tau, dist, 1)
+        assert np.abs(l - g["cbca1it_l"]).max() <= 1e-6, name
+        assert np.abs(r - g["cbca1it_r"]).max() <= 1e-6, name
+        l, r = pf.cost_volume_aggregation(g["left"], g["right"], g["sgm_l"], g["sgm_r"], tau, dist, hp["it2"])
+        scale = max(1.0, float(np.abs(g["sgm_l"]).max()))
+        assert np.abs(l - g["cbca2_l"]).max() <= 16e-6 * scale, name   # 16 iterations, O(scale) costs
+        assert np.abs(r - g["cbca2_r"]).max() <= 16e-6 * scale, name
+
+
+def test_golden_sgm_each_direction_bit_exact(pf, golden_cases):
+    for name, g in golden_cases:
+        hp = hp_of(g)
+        for dname, r in DIRS.items():
+            p1 = hp["sgm_P1"] if r[0] == 0 else hp["sgm_P1"] / hp["sgm_V"]
+            for side, ch in (("l", "L"), ("r", "R")):
+                v = g["cbca1_" + side].copy()
+                out = pf.semi_global_matching(g["left"], g["right"], v, r, p1, hp["sgm_P2"], hp["sgm_Q1"],
+                                              hp["sgm_Q2"], hp["sgm_D"], ch)
+                assert out is v, "must mutate and return its argument (pf:544,568)"
+                assert_bits(v, g["sgm_%s_%s" % (dname, side)], "%s sgm %s %s" % (name, dname, ch))
+
+
+def test_golden_sgm_average_bit_exact(pf, golden_cases):
+    for name, g in golden_cases:
+        hp = hp_of(g)
+        a, b = g["cbca1_l"].copy(), g["cbca1_r"].copy()
+        l, r = pf.SGM_average(a, b, g["left"], g["right"], hp["sgm_P1"], hp["sgm_P2"], hp["sgm_Q1"], hp["sgm_Q2"],
+                              hp["sgm_D"], hp["sgm_V"])
+        assert_bits(l, g["sgm_l"], name + " sgm_l")
+        assert_bits(r, g["sgm_r"], name + " sgm_r")
+        assert_bits(a, g["sgm_l"], name + " argument mutated like the reference")
+
+
+def test_golden_wta_to_bilateral_bit_exact(pf, golden_cases):
+    for name, g in golden_cases:
+        hp = hp_of(g)
+        D = g["cv_l"].shape[0]
+        dl, dr = pf.disparity_prediction(g["cbca2_l"], g["cbca2_r"])
+        assert_bits(dl, g["wta_l"], name + " wta_l")
+        assert_bits(dr, g["wta_r"], name + " wta_r")
+        assert_bits(pf.interpolation(g["wta_l"], g["wta_r"], D), g["interp"], name + " interp")
+        assert_bits(pf.subpixel_enhance(g["interp"], g["cbca2_l"]), g["subpixel"], name + " subpixel")
+        assert_bits(pf.median_filter(g["subpixel"], 5, 5), g["median"], name + " median")
+        assert_bits(pf.bilateral_filter(g["left"], g["median"], 5, 5, 0, hp["blur_sigma"], hp["blur_threshold"]),
+                    g["bilateral"], name + " bilateral")
+
+
+def test_golden_features(pf, golden_cases, net_layers):
+    from model import NET
+    net = NET(None, input_patch_size=11, batch_size=1, device="cuda").set_layers(net_layers)
+    for name, g in golden_cases:
+        fl, fr = pf.compute_features(g["left"], g["right"], 11, 11, net)
+        assert fl.shape == g["fl"].shape and fl.dtype == np.float32
+        assert np.abs(fl - g["fl"]).max() <= 1e-5, name   # vs the float64-accumulating restatement
+        assert np.abs(fr - g["fr"]).max() <= 1e-5, name
+
+
+def test_golden_whole_pair_reference_order(sd, golden_cases, net_layers):
+    """StereoMatcher.match (the timed region) with the bit-exact stage variants, fed the golden features' images:
+    features differ from the oracle's by <= 1e-5, so the final map is compared with a tolerance and a flip count."""
+    import _hipabi as hip
+    from model import NET
+    net = NET(None, input_patch_size=11, batch_size=1, device="cuda").set_layers(net_layers)
+    for name, g in golden_cases:
+        D = g["cv_l"].shape[0]
+        m = sd.StereoMatcher(net, cv_mode=hip.MCCNN_CV_EXACT, cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER)
+        keep = {}
+        out = m.match(dev(g["left"]), dev(g["right"]), D, keep=keep).cpu().numpy()
+        flips = int((keep["wta"][0].cpu().numpy() != g["wta_l"]).sum())
+        close = np.isclose(out, g["bilateral"], atol=1e-3, equal_nan=True).mean()
+        assert flips <= max(2, out.size // 100), "%s: %d WTA flips" % (name, flips)
+        assert close >= 0.97, "%s: only %.3f of pixels within 1e-3 px" % (name, close)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# (2) oracle on seeded inputs, mid sizes, ragged shapes
+# ---------------------------------------------------------------------------------------------------------------
+def _rand_vol(rng, D, H, W):
+    return (-rng.random((D, H, W), dtype=np.float32)).astype(np.float32)
+
+
+@pytest.mark.parametrize("H,W,D", [(37, 83, 24), (70, 130, 64), (33, 300, 256), (20, 450, 400), (9, 21, 2)])
+def test_oracle_sgm_passes_and_average(pf, H, W, D):
+    import oracle as o
+    import synthetic
+    rng = np.random.default_rng(H * 1000 + W)
+    L, R, _, _, _ = synthetic.make_pair(H, W, max(D, 4), seed=H + W)
+    for r in DIRS.values():
+        for ch in "LR":
+            v0 = _rand_vol(rng, D, H, W)
+            a, b = v0.copy(), v0.copy()
+            o.semi_global_matching(L, R, a, r, 2.3, 55.9, 4, 8, 0.08, ch)
+            pf.semi_global_matching(L, R, b, r, 2.3, 55.9, 4, 8, 0.08, ch)
+            assert_bits(b, a, "sgm r=%s %s %dx%dx%d" % (r, ch, H, W, D))
+    vl, vr = _rand_vol(rng, D, H, W), _rand_vol(rng, D, H, W)
+    ol, orr = o.SGM_average(vl.copy(), vr.copy(), L, R, 2.3, 55.9, 4, 8, 0.08, 1.5)
+    gl, gr = pf.SGM_average(vl.copy(), vr.copy(), L, R, 2.3, 55.9, 4, 8, 0.08, 1.5)
+    assert_bits(gl, ol, "SGM_average L")
+    assert_bits(gr, orr, "SGM_average R")
+
+
+def test_oracle_sgm_penalty_classes_all_exercised(pf):
+    """A high-contrast pair drives every (D1,D2) threshold combination, with non-power-of-two Q so P/Q rounds."""
+    import oracle as o
+    rng = np.random.default_rng(5)
+    H, W, D = 24, 40, 16
+    L = rng.choice([0.0, 0.05, 0.2, 1.0], size=(H, W, 1)).astype(np.float32)
+    R = rng.choice([0.0, 0.07, 0.3, 1.0], size=(H, W, 1)).astype(np.float32)
+    for r in DIRS.values():
+        for ch in "LR":
+            v0 = _rand_vol(rng, D, H, W)
+            a, b = v0.copy(), v0.copy()
+            o.semi_global_matching(L, R, a, r, 1.7, 31.3, 3, 7, 0.08, ch)
+            pf.semi_global_matching(L, R, b, r, 1.7, 31.3, 3, 7, 0.08, ch)
+            assert_bits(b, a, "sgm classes r=%s %s" % (r, ch))
+
+
+@pytest.mark.parametrize("H,W,D", [(45, 100, 20), (64, 128, 33), (100, 70, 8)])
+def test_oracle_cbca_and_cross(pf, sd, H, W, D):
+    import oracle as o
+    import synthetic
+    rng = np.random.default_rng(W)
+    L, R, _, _, _ = synthetic.make_pair(H, W, 16, seed=W)
+    arms_o, cnt_o = o.cross_arms(L, 0.02, 14)
+    arms, cnt = sd.cross_arms(dev(L[:, :, 0]), 0.02, 14)
+    assert np.array_equal(arms.cpu().numpy(), arms_o)
+    assert np.array_equal(cnt.cpu().numpy(), cnt_o)
+    assert cnt_o.max() > 30, "test image must have non-trivial support regions"
+    vl, vr = _rand_vol(rng, D, H, W), _rand_vol(rng, D, H, W)
+    ol, orr = o.cost_volume_aggregation(L, R, vl, vr, 0.02, 14, 3)
+    pf.CBCA_ORDER = "reference"
+    try:
+        gl, gr = pf.cost_volume_aggregation(L, R, vl, vr, 0.02, 14, 3)
+    finally:
+        pf.CBCA_ORDER = "separable"
+    assert_bits(gl, ol, "cbca reference order L")
+    assert_bits(gr, orr, "cbca reference order R")
+    sl, sr = pf.cost_volume_aggregation(L, R, vl, vr, 0.02, 14, 3)
+    assert np.abs(sl - ol).max() <= 3e-6 and np.abs(sr - orr).max() <= 3e-6
+
+
+def test_oracle_cbca_long_arms_other_distance(pf):
+    """Flat image: every arm hits the distance limit; also a distance threshold other than the default 14."""
+    import oracle as o
+    rng = np.random.default_rng(1)
+    H, W, D = 50, 90, 5
+    L = np.zeros((H, W, 1), np.float32)
+    R = np.zeros((H, W, 1), np.float32)
+    R[:, ::7] = 1.0
+    vl, vr = _rand_vol(rng, D, H, W), _rand_vol(rng, D, H, W)
+    for dist in (14, 6, 20):
+        ol, orr = o.cost_volume_aggregation(L, R, vl, vr, 0.02, dist, 2)
+        pf.CBCA_ORDER = "reference"
+        try:
+            gl, gr = pf.cost_volume_aggregation(L, R, vl, vr, 0.02, dist, 2)
+        finally:
+            pf.CBCA_ORDER = "separable"
+        assert_bits(gl, ol, "flat image, distance %d" % dist)
+        assert_bits(gr, orr, "striped image, distance %d" % dist)
+        sl, _ = pf.cost_volume_aggregation(L, R, vl, vr, 0.02, dist, 2)
+        assert np.abs(sl - ol).max() <= 2e-5   # up to (2*19+1)^2 terms per sum here
+
+
+@pytest.mark.parametrize("H,W,D", [(21, 70, 40), (40, 200, 64), (12, 300, 256)])
+def test_oracle_cost_volume(pf, H, W, D):
+    import oracle as o
+    rng = np.random.default_rng(D)
+    fl = rng.standard_normal((H, W, 64)).astype(np.float32)
+    fr = rng.standard_normal((H, W, 64)).astype(np.float32)
+    fl /= np.linalg.norm(fl, axis=-1, keepdims=True)
+    fr /= np.linalg.norm(fr, axis=-1, keepdims=True)
+    ol, orr = o.compute_cost_volume(fl, fr, D)
+    pf.COST_VOLUME_MODE = "exact"
+    gl, gr = pf.compute_cost_volume(fl, fr, D)
+    assert_bits(gl, ol, "cost volume L exact")
+    assert_bits(gr, orr, "cost volume R exact")
+    pf.COST_VOLUME_MODE = "mfma"
+    try:
+        ml, mr = pf.compute_cost_volume(fl, fr, D)
+    finally:
+        pf.COST_VOLUME_MODE = "exact"
+    assert np.abs(ml - ol).max() <= 2e-6 and np.abs(mr - orr).max() <= 2e-6
+
+
+def test_cost_volume_rejects_degenerate_disparity_range(pf):
+    import _hipabi
+    f = np.zeros((4, 10, 64), np.float32)
+    with pytest.raises(_hipabi.MccnnHipError):
+        pf.compute_cost_volume(f, f, 9)   # D > W-2: the reference's own border recurrence is degenerate there
+
+
+@pytest.mark.parametrize("H,W,D", [(30, 50, 12), (64, 200, 70)])
+def test_oracle_wta_ties_and_postprocessing(pf, H, W, D):
+    import oracle as o
+    rng = np.random.default_rng(H)
+    # quantised costs -> many exact ties: the first minimum must win
+    vl = (rng.integers(0, 6, size=(D, H, W)) * 0.25).astype(np.float32)
+    vr = (rng.integers(0, 6, size=(D, H, W)) * 0.25).astype(np.float32)
+    odl, odr = o.disparity_prediction(vl, vr)
+    gdl, gdr = pf.disparity_prediction(vl, vr)
+    assert_bits(gdl, odl, "wta ties L")
+    assert_bits(gdr, odr, "wta ties R")
+    # random maps exercise all three LR states and every interpolation branch
+    dl = rng.integers(0, D, size=(H, W)).astype(np.float32)
+    dr = rng.integers(0, D, size=(H, W)).astype(np.float32)
+    dl[:, : W // 2] = 3.0
+    dr[:, : W // 2] = 3.0
+    st = o.lr_status(dl, dr, D)
+    assert set(np.unique(st)) == {0, 1, 2}
+    assert_bits(pf.interpolation(dl, dr, D), o.interpolation(dl, dr, D), "interpolation")
+    di = o.interpolation(dl, dr, D)
+    vol = rng.random((D, H, W), dtype=np.float32)
+    osub = o.subpixel_enhance(di, vol)
+    assert_bits(pf.subpixel_enhance(di, vol), osub, "subpixel")
+    flat = np.zeros((D, H, W), np.float32)   # zero denominators -> nan/inf must propagate identically
+    with np.errstate(all="ignore"):
+        onan = o.subpixel_enhance(di, flat)
+    gnan = pf.subpixel_enhance(di, flat)
+    assert np.array_equal(np.isnan(onan), np.isnan(gnan))
+    assert_bits(pf.median_filter(osub, 5, 5), o.median_filter(osub, 5, 5), "median 5x5")
+    assert_bits(pf.median_filter(osub, 3, 7), o.median_filter(osub, 3, 7), "median 3x7")
+    assert_bits(pf.median_filter(gnan, 5, 5), o.median_filter(onan, 5, 5), "median with nan")
+    img = rng.standard_normal((H, W, 1)).astype(np.float32) * 2
+    om = o.median_filter(osub, 5, 5)
+    assert_bits(pf.bilateral_filter(img, om, 5, 5, 0, 6, 2), o.bilateral_filter(img, om, 5, 5, 0, 6, 2), "bilateral")
+    assert_bits(pf.bilateral_filter(img, om, 3, 5, 0, 2.5, 0.7), o.bilateral_filter(img, om, 3, 5, 0, 2.5, 0.7),
+                "bilateral 3x5")
+
+
+def test_layout_round_trip(sd):
+    rng = np.random.default_rng(0)
+    for (D, H, W) in [(5, 7, 9), (64, 33, 65), (130, 20, 70)]:
+        v = rng.standard_normal((D, H, W)).astype(np.float32)
+        hwd = sd.dhw_to_hwd(dev(v))
+        assert hwd.shape == (H, W, (D + 3) // 4 * 4)
+        assert np.array_equal(hwd.cpu().numpy()[:, :, :D], np.transpose(v, (1, 2, 0)))
+        assert np.array_equal(sd.hwd_to_dhw(hwd, D).cpu().numpy(), v)
+
+
+def test_torch_tensor_inputs_stay_on_device(pf):
+    v = torch.rand((6, 12, 20), device="cuda") * -1
+    dl, dr = pf.disparity_prediction(v, v)
+    assert torch.is_tensor(dl) and dl.is_cuda and dl.shape == (12, 20)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# (3) full-size properties (no oracle at these sizes)
+# ---------------------------------------------------------------------------------------------------------------
+def test_full_size_properties_cfg2(sd):
+    """Middlebury-half sized volume (750x500, D=256): size-independent invariants of the kernels."""
+    import _hipabi as hip
+    H, W, D = 500, 750, 256
+    g = torch.Generator(device="cuda").manual_seed(0)
+    v = -torch.rand((D, H, W), device="cuda", generator=g)
+    # layout round trip is the identity
+    hwd = sd.dhw_to_hwd(v)
+    assert torch.equal(sd.hwd_to_dhw(hwd, D), v)
+    # WTA == argmin (first minimum)
+    assert torch.equal(sd.wta(v), torch.argmin(v, dim=0).float())
+    # CBCA of a constant volume is that constant (averaging is a partition of unity) and is bounded by min/max
+    img = (torch.rand((H, W), device="cuda", generator=g) * 4).round() / 4
+    arms, cnt = sd.cross_arms(img, 0.02, 14)
+    c = torch.full((4, H, W), -0.375, device="cuda")
+    res, _ = sd.cbca(c, torch.empty_like(c), arms, cnt, 3, 14)
+    assert torch.equal(res, torch.full_like(res, -0.375))
+    res, _ = sd.cbca(v[:8].clone(), torch.empty((8, H, W), device="cuda"), arms, cnt, 2, 14)
+    assert res.min() >= v[:8].min() - 1e-6 and res.max() <= v[:8].max() + 1e-6
+    # SGM: adding a constant to the whole volume adds the same constant to the output of a pass (the recurrence adds
+    # min(...) of the previous pixel and subtracts its min_k, which shift together) - checked on integer-valued
+    # costs and dyadic penalties, where float32 arithmetic is exact
+    vi = torch.randint(0, 64, (D, H, W), device="cuda", generator=g).float()
+    scratch = sd.sgm_scratch(H, W, D, vi.device)
+    outs = []
+    for shift in (0.0, 32.0):
+        h = sd.dhw_to_hwd(vi + shift)
+        sd.sgm_pass_hwd(img, img, [h], [hip.MCCNN_SIDE_LEFT], D, (0, 1), 2.0, 56.0, 4.0, 8.0, 0.08, scratch)
+        sd.sgm_pass_hwd(img, img, [h], [hip.MCCNN_SIDE_LEFT], D, (1, 0), 2.0, 56.0, 4.0, 8.0, 0.08, scratch)
+        outs.append(sd.hwd_to_dhw(h, D))
+    assert torch.equal(outs[1], outs[0] + 32.0)
+    # first scan line of a pass is untouched
+    h = sd.dhw_to_hwd(vi)
+    sd.sgm_pass_hwd(img, img, [h], [hip.MCCNN_SIDE_RIGHT], D, (0, -1), 2.0, 56.0, 4.0, 8.0, 0.08, scratch)
+    assert torch.equal(sd.hwd_to_dhw(h, D)[:, :, W - 1], vi[:, :, W - 1])
