@@ -96,16 +96,19 @@ def cross_region_list(arms, distance_threshold):
 
 
 # ---- a4 ----------------------------------------------------------------------------------------------------------
-def cbca(vol, tmp, arms, count, iterations, distance_threshold, order=hip.MCCNN_CBCA_SEPARABLE):
+def cbca(vol, tmp, arms, count, iterations, distance_threshold, order=hip.MCCNN_CBCA_SEPARABLE, timer=None):
     """`iterations` rounds of cross-based averaging.  Ping-pongs between `vol` and `tmp` (same shape);
     returns (result, spare) - the input buffer is clobbered when iterations >= 2, the reference's is not, so
     callers that need the input keep their own copy."""
     D, H, W = vol.shape
     lib = hip.load()
     src, dst = vol, tmp
+    timer = timer or _NO_TIMER
     for _ in range(int(iterations)):
+        timer.start("cbca_iter")
         hip.check(lib.mccnn_cbca_iter(hip.ptr(src), hip.ptr(dst), hip.ptr(arms), hip.ptr(count), D, H, W,
                                       int(distance_threshold), int(order), hip.stream()), "mccnn_cbca_iter")
+        timer.stop()
         src, dst = dst, src
     return src, dst
 
@@ -299,10 +302,10 @@ class StereoMatcher(object):
         timer.stop()
 
         t1d, t2d = ws["t1"][:nd].view(dhw), ws["t2"][:nd].view(dhw)
-        timer.start("cbca1")
-        lcv, t1d = cbca(lcv, t1d, arms_l, cnt_l, hp["cbca_num_iterations1"], hp["cbca_distance"], self.cbca_order)
-        rcv, t2d = cbca(rcv, t2d, arms_r, cnt_r, hp["cbca_num_iterations1"], hp["cbca_distance"], self.cbca_order)
-        timer.stop()
+        lcv, t1d = cbca(lcv, t1d, arms_l, cnt_l, hp["cbca_num_iterations1"], hp["cbca_distance"], self.cbca_order,
+                        timer)
+        rcv, t2d = cbca(rcv, t2d, arms_r, cnt_r, hp["cbca_num_iterations1"], hp["cbca_distance"], self.cbca_order,
+                        timer)
         if keep is not None:
             keep["cbca1"] = (lcv.clone(), rcv.clone())
 
@@ -320,10 +323,10 @@ class StereoMatcher(object):
         if keep is not None:
             keep["sgm"] = (lcv.clone(), rcv.clone())
 
-        timer.start("cbca2")
-        lcv, t1d = cbca(lcv, t1d, arms_l, cnt_l, hp["cbca_num_iterations2"], hp["cbca_distance"], self.cbca_order)
-        rcv, t2d = cbca(rcv, t2d, arms_r, cnt_r, hp["cbca_num_iterations2"], hp["cbca_distance"], self.cbca_order)
-        timer.stop()
+        lcv, t1d = cbca(lcv, t1d, arms_l, cnt_l, hp["cbca_num_iterations2"], hp["cbca_distance"], self.cbca_order,
+                        timer)
+        rcv, t2d = cbca(rcv, t2d, arms_r, cnt_r, hp["cbca_num_iterations2"], hp["cbca_distance"], self.cbca_order,
+                        timer)
         if keep is not None:
             keep["cbca2"] = (lcv.clone(), rcv.clone())
 

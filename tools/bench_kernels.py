@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmarks of libmccnn_hip.so at a BASELINE config (HIP events on the launch stream).
+
+    python tools/bench_kernels.py [--config cfg2] [--iters 20] [--only cbca_iter,sgm_pass]
+
+Prints one line per kernel: avg ms per launch, algorithmic GB/s, fraction of the 8 TB/s HBM peak.  Meant to be run
+under rocprofv3 (--kernel-trace --stats, or --pmc ...) when a single kernel is being tuned.
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mc-cnn-python_amd", "src"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import _hipabi as hip  # noqa: E402
+import stereo_device as sd  # noqa: E402
+import synthetic  # noqa: E402
+from bench import CONFIGS, HBM_PEAK_GBS  # noqa: E402
+
+
+def timeit(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    a = torch.cuda.Event(enable_timing=True)
+    b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    hip.require_device()
+    H, W, D = CONFIGS[args.config]
+    only = set(x for x in args.only.split(",") if x)
+    L, R, _, _, _ = synthetic.make_pair(H, W, D, seed=100)
+    dl, dr = torch.from_numpy(L[:, :, 0]).cuda(), torch.from_numpy(R[:, :, 0]).cuda()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    va = -torch.rand((D, H, W), device="cuda", generator=g)
+    vb = torch.empty_like(va)
+    vol_bytes = 4.0 * D * H * W
+    arms, cnt = sd.cross_arms(dl, 0.02, 14)
+    rows = []
+
+    def add(name, fn, nbytes):
+        if only and name not in only:
+            return
+        ms = timeit(fn, args.iters)
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        rows.append((name, ms, gbs))
+        print("%-22s %8.4f ms  %8.1f GB/s  %5.1f%% of HBM peak" % (name, ms, gbs, 100 * gbs / HBM_PEAK_GBS), flush=True)
+
+    add("cbca_iter", lambda: sd.cbca(va, vb, arms, cnt, 1, 14, hip.MCCNN_CBCA_SEPARABLE), 2 * vol_bytes)
+    add("cbca_iter_reforder", lambda: sd.cbca(va, vb, arms, cnt, 1, 14, hip.MCCNN_CBCA_REFERENCE_ORDER), 2 * vol_bytes)
+    hwd = sd.dhw_to_hwd(va)
+    hwd2 = sd.dhw_to_hwd(vb)
+    scratch = sd.sgm_scratch(H, W, D, va.device)
+    for name, r in (("sgm_pass_h", (0, 1)), ("sgm_pass_v", (1, 0))):
+        add(name, lambda r=r: sd.sgm_pass_hwd(dl, dr, [hwd, hwd2], [0, 1], D, r, 2.3, 55.9, 4.0, 8.0, 0.08, scratch),
+            4 * vol_bytes)
+    add("dhw_to_hwd", lambda: sd.dhw_to_hwd(va, hwd), 2 * vol_bytes)
+    add("hwd_to_dhw", lambda: sd.hwd_to_dhw(hwd, D, vb), 2 * vol_bytes)
+    add("wta", lambda: sd.wta(va), vol_bytes)
+    fl = torch.nn.functional.normalize(torch.randn((H, W, 64), device="cuda", generator=g), dim=-1).contiguous()
+    fr = torch.nn.functional.normalize(torch.randn((H, W, 64), device="cuda", generator=g), dim=-1).contiguous()
+    add("cost_volume_exact", lambda: sd.cost_volume(fl, fr, D, hip.MCCNN_CV_EXACT, out=(va, vb)), 2 * vol_bytes)
+    add("cost_volume_mfma", lambda: sd.cost_volume(fl, fr, D, hip.MCCNN_CV_MFMA, out=(va, vb)), 2 * vol_bytes)
+
+
+if __name__ == "__main__":
+    main()
