@@ -20,7 +20,7 @@
  *   features  [H][W][C]     float32, C = 64 (NET.features, NHWC)
  *   volume    "DHW" [D][H][W]   - the reference's layout; cost volume, CBCA, WTA, sub-pixel use it
  *             "HWD" [H][W][Dp]  - pixel-major, Dp = mccnn_hwd_pitch(D); the SGM scanline kernels use it
- *   arms      [H][W][4]     uint8  (up, down, left, right) cross-arm lengths, self excluded
+ *   support   [H][W]        8-byte records {uint8 up, down, left, right; int32 count} (mccnn_support_t)
  *   maps      [H][W]        float32 disparity maps, int32 status / region counts
  */
 #ifndef MCCNN_H
@@ -59,23 +59,31 @@ int mccnn_cost_volume(const float *fl, const float *fr, int H, int W, int C, int
                       mccnn_stream_t stream);
 
 /* ---- a3  compute_cross_region (pf:571-657) ----------------------------------------------------------------
- * Arm lengths (<= L-1 per side, anchor-relative threshold |I(q)-I(p)| < tau) and the region size
- * count[h,w] = sum over the vertical arm of (left+right+1).  The reference's explicit coordinate list
- * [H][W][(2L)^2][2] (padded with -1) is produced by mccnn_cross_region_list for API compatibility only. */
-int mccnn_cross_arms(const float *image, int H, int W, float tau, int L, uint8_t *arms, int32_t *count,
+ * Per pixel: the four arm lengths (<= L-1 per side, anchor-relative threshold |I(q)-I(p)| < tau) and the region
+ * size count = sum over the vertical arm of (left+right+1), packed in one 8-byte record so that the aggregation
+ * kernel fetches both with one load.  The reference's explicit coordinate list [H][W][(2L)^2][2] (padded with -1)
+ * is produced by mccnn_cross_region_list for API compatibility only. */
+typedef struct mccnn_support {
+    uint8_t arm[4]; /* up, down, left, right - number of pixels accepted in that direction, self excluded */
+    int32_t count;  /* |U(p)|, the reference's union_region_num */
+} mccnn_support_t;  /* 8 bytes, plane layout [H][W] */
+int mccnn_cross_arms(const float *image, int H, int W, float tau, int L, mccnn_support_t *support,
                      mccnn_stream_t stream);
-int mccnn_cross_region_list(const uint8_t *arms, int H, int W, int L, int32_t *region, mccnn_stream_t stream);
+int mccnn_cross_region_list(const mccnn_support_t *support, int H, int W, int L, int32_t *region,
+                            mccnn_stream_t stream);
 
 /* ---- a4  cost_volume_aggregation, ONE iteration on ONE volume (pf:149-163) -----------------------------------
  * out[d,p] = (sum_{q in U(p)} in[d,q]) / count[p];  in != out (ping-pong; the reference does not mutate either).
- * L is the distance threshold the arms were built with (arms < L; supported: L <= 32).
- * order MCCNN_CBCA_SEPARABLE: horizontal-arm sums then vertical-arm sums (same set, float32 rounding differs
- * from the reference by <= 1e-6 per iteration on O(1) costs); MCCNN_CBCA_REFERENCE_ORDER: the reference's flat
- * running sum (vertical arm self,up..,down.. x horizontal arm self,left..,right..), bit-exact, slower. */
+ * L is the distance threshold the support plane was built with (arms < L; supported: L <= 32).
+ * order MCCNN_CBCA_SEPARABLE: horizontal-arm sums then vertical-arm sums evaluated through float64 prefix sums -
+ * the correctly rounded region sum, within <= 1e-6 per iteration (O(1) costs) of the reference's sequential float32
+ * sum, cost independent of the arm lengths; volumes must be finite (an inf/nan would poison its whole row).
+ * MCCNN_CBCA_REFERENCE_ORDER: the reference's flat running sum (vertical arm self,up..,down.. x horizontal arm
+ * self,left..,right..), bit-exact, slower. */
 #define MCCNN_CBCA_SEPARABLE 0
 #define MCCNN_CBCA_REFERENCE_ORDER 1
-int mccnn_cbca_iter(const float *in, float *out, const uint8_t *arms, const int32_t *count, int D, int H, int W,
-                    int L, int order, mccnn_stream_t stream);
+int mccnn_cbca_iter(const float *in, float *out, const mccnn_support_t *support, int D, int H, int W, int L, int order,
+                    mccnn_stream_t stream);
 
 /* ---- layout changes between DHW and HWD ------------------------------------------------------------------- */
 int mccnn_hwd_pitch(int D); /* Dp: D rounded up to a multiple of 4 (16-byte rows) */

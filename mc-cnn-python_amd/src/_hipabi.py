@@ -28,9 +28,9 @@ SIGNATURES = {
     "mccnn_version": (_i, []),
     "mccnn_last_error_string": (ctypes.c_char_p, []),
     "mccnn_cost_volume": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
-    "mccnn_cross_arms": (_i, [_vp, _i, _i, _f, _i, _vp, _vp, _vp]),
+    "mccnn_cross_arms": (_i, [_vp, _i, _i, _f, _i, _vp, _vp]),
     "mccnn_cross_region_list": (_i, [_vp, _i, _i, _i, _vp, _vp]),
-    "mccnn_cbca_iter": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mccnn_cbca_iter": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mccnn_hwd_pitch": (_i, [_i]),
     "mccnn_dhw_to_hwd": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "mccnn_hwd_to_dhw": (_i, [_vp, _vp, _i, _i, _i, _vp]),

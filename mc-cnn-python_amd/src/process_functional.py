@@ -88,9 +88,9 @@ def compute_cross_region(image, intensity_threshold, distance_threshold):
     """pf:571-657: (union_region int32 [H,W,(2L)^2,2] padded with -1, union_region_num int32 [H,W]).
     Only for API compatibility / small images - the aggregation below never materialises the lists."""
     img, was_np = _img(image)
-    arms, count = sd.cross_arms(img, intensity_threshold, int(distance_threshold))
-    region = sd.cross_region_list(arms, int(distance_threshold))
-    return _ret(region, was_np), _ret(count, was_np)
+    support = sd.cross_arms(img, intensity_threshold, int(distance_threshold))
+    region = sd.cross_region_list(support, int(distance_threshold))
+    return _ret(region, was_np), _ret(sd.support_count(support).contiguous(), was_np)
 
 
 def cost_volume_aggregation(left_image, right_image, left_cost_volume, right_cost_volume,
@@ -103,8 +103,8 @@ def cost_volume_aggregation(left_image, right_image, left_cost_volume, right_cos
         v, was_np = _dev(vol)
         if torch.is_tensor(vol) and v.data_ptr() == vol.data_ptr():
             v = v.clone()  # the ping-pong clobbers its input; the reference leaves the caller's array alone
-        arms, count = sd.cross_arms(img, intensity_threshold, int(distance_threshold))
-        res, _spare = sd.cbca(v, torch.empty_like(v), arms, count, int(max_average_time), int(distance_threshold),
+        support = sd.cross_arms(img, intensity_threshold, int(distance_threshold))
+        res, _spare = sd.cbca(v, torch.empty_like(v), support, int(max_average_time), int(distance_threshold),
                               _CBCA_ORDERS[CBCA_ORDER])
         outs.append(_ret(res, was_np))
     return outs[0], outs[1]

@@ -77,26 +77,36 @@ def cost_volume(fl, fr, ndisp, mode=hip.MCCNN_CV_EXACT, out=None):
 
 # ---- a3 ----------------------------------------------------------------------------------------------------------
 def cross_arms(image, intensity_threshold, distance_threshold):
-    """image [H,W] -> (arms uint8 [H,W,4] = up,down,left,right; count int32 [H,W])."""
+    """image [H,W] -> support plane, int32 [H,W,2]: word 0 = four uint8 arm lengths (up, down, left, right), word 1 =
+    region size (mccnn_support_t).  support_arms()/support_count() give the two parts as separate views."""
     H, W = image.shape
-    arms = torch.empty((H, W, 4), dtype=torch.uint8, device=image.device)
-    count = torch.empty((H, W), dtype=torch.int32, device=image.device)
+    support = torch.empty((H, W, 2), dtype=torch.int32, device=image.device)
     hip.check(hip.load().mccnn_cross_arms(hip.ptr(image), H, W, _f32(intensity_threshold), int(distance_threshold),
-                                          hip.ptr(arms), hip.ptr(count), hip.stream()), "mccnn_cross_arms")
-    return arms, count
+                                          hip.ptr(support), hip.stream()), "mccnn_cross_arms")
+    return support
 
 
-def cross_region_list(arms, distance_threshold):
-    H, W, _ = arms.shape
+def support_arms(support):
+    """uint8 [H,W,4] view: up, down, left, right."""
+    return support.view(torch.uint8)[:, :, :4]
+
+
+def support_count(support):
+    """int32 [H,W] view of the region sizes (the reference's union_region_num)."""
+    return support[:, :, 1]
+
+
+def cross_region_list(support, distance_threshold):
+    H, W, _ = support.shape
     L = int(distance_threshold)
-    region = torch.empty((H, W, (2 * L) ** 2, 2), dtype=torch.int32, device=arms.device)
-    hip.check(hip.load().mccnn_cross_region_list(hip.ptr(arms), H, W, L, hip.ptr(region), hip.stream()),
+    region = torch.empty((H, W, (2 * L) ** 2, 2), dtype=torch.int32, device=support.device)
+    hip.check(hip.load().mccnn_cross_region_list(hip.ptr(support), H, W, L, hip.ptr(region), hip.stream()),
               "mccnn_cross_region_list")
     return region
 
 
 # ---- a4 ----------------------------------------------------------------------------------------------------------
-def cbca(vol, tmp, arms, count, iterations, distance_threshold, order=hip.MCCNN_CBCA_SEPARABLE, timer=None):
+def cbca(vol, tmp, support, iterations, distance_threshold, order=hip.MCCNN_CBCA_SEPARABLE, timer=None):
     """`iterations` rounds of cross-based averaging.  Ping-pongs between `vol` and `tmp` (same shape);
     returns (result, spare) - the input buffer is clobbered when iterations >= 2, the reference's is not, so
     callers that need the input keep their own copy."""
@@ -106,7 +116,7 @@ def cbca(vol, tmp, arms, count, iterations, distance_threshold, order=hip.MCCNN_
     timer = timer or _NO_TIMER
     for _ in range(int(iterations)):
         timer.start("cbca_iter")
-        hip.check(lib.mccnn_cbca_iter(hip.ptr(src), hip.ptr(dst), hip.ptr(arms), hip.ptr(count), D, H, W,
+        hip.check(lib.mccnn_cbca_iter(hip.ptr(src), hip.ptr(dst), hip.ptr(support), D, H, W,
                                       int(distance_threshold), int(order), hip.stream()), "mccnn_cbca_iter")
         timer.stop()
         src, dst = dst, src
@@ -297,14 +307,14 @@ class StereoMatcher(object):
             keep["cv"] = (lcv.clone(), rcv.clone())
 
         timer.start("cross_arms")
-        arms_l, cnt_l = cross_arms(L, hp["cbca_intensity"], hp["cbca_distance"])
-        arms_r, cnt_r = cross_arms(R, hp["cbca_intensity"], hp["cbca_distance"])
+        sup_l = cross_arms(L, hp["cbca_intensity"], hp["cbca_distance"])
+        sup_r = cross_arms(R, hp["cbca_intensity"], hp["cbca_distance"])
         timer.stop()
 
         t1d, t2d = ws["t1"][:nd].view(dhw), ws["t2"][:nd].view(dhw)
-        lcv, t1d = cbca(lcv, t1d, arms_l, cnt_l, hp["cbca_num_iterations1"], hp["cbca_distance"], self.cbca_order,
+        lcv, t1d = cbca(lcv, t1d, sup_l, hp["cbca_num_iterations1"], hp["cbca_distance"], self.cbca_order,
                         timer)
-        rcv, t2d = cbca(rcv, t2d, arms_r, cnt_r, hp["cbca_num_iterations1"], hp["cbca_distance"], self.cbca_order,
+        rcv, t2d = cbca(rcv, t2d, sup_r, hp["cbca_num_iterations1"], hp["cbca_distance"], self.cbca_order,
                         timer)
         if keep is not None:
             keep["cbca1"] = (lcv.clone(), rcv.clone())
@@ -323,9 +333,9 @@ class StereoMatcher(object):
         if keep is not None:
             keep["sgm"] = (lcv.clone(), rcv.clone())
 
-        lcv, t1d = cbca(lcv, t1d, arms_l, cnt_l, hp["cbca_num_iterations2"], hp["cbca_distance"], self.cbca_order,
+        lcv, t1d = cbca(lcv, t1d, sup_l, hp["cbca_num_iterations2"], hp["cbca_distance"], self.cbca_order,
                         timer)
-        rcv, t2d = cbca(rcv, t2d, arms_r, cnt_r, hp["cbca_num_iterations2"], hp["cbca_distance"], self.cbca_order,
+        rcv, t2d = cbca(rcv, t2d, sup_r, hp["cbca_num_iterations2"], hp["cbca_distance"], self.cbca_order,
                         timer)
         if keep is not None:
             keep["cbca2"] = (lcv.clone(), rcv.clone())

@@ -65,9 +65,9 @@ def test_golden_cross_region(pf, sd, golden_cases):
         hp = hp_of(g)
         for side in "lr":
             img = dev(g["left" if side == "l" else "right"][:, :, 0])
-            arms, cnt = sd.cross_arms(img, hp["cbca_intensity"], int(hp["cbca_distance"]))
-            assert np.array_equal(arms.cpu().numpy(), g["arms_" + side]), name
-            assert np.array_equal(cnt.cpu().numpy(), g["region_num_" + side]), name
+            sup = sd.cross_arms(img, hp["cbca_intensity"], int(hp["cbca_distance"]))
+            assert np.array_equal(sd.support_arms(sup).cpu().numpy(), g["arms_" + side]), name
+            assert np.array_equal(sd.support_count(sup).cpu().numpy(), g["region_num_" + side]), name
         if "region_l_crop" in g:
             reg, num = pf.compute_cross_region(g["left"], hp["cbca_intensity"], hp["cbca_distance"])
             assert reg.dtype == np.int32 and reg.shape == (g["left"].shape[0], g["left"].shape[1], 784, 2)
@@ -225,9 +225,9 @@ def test_oracle_cbca_and_cross(pf, sd, H, W, D):
     rng = np.random.default_rng(W)
     L, R, _, _, _ = synthetic.make_pair(H, W, 16, seed=W)
     arms_o, cnt_o = o.cross_arms(L, 0.02, 14)
-    arms, cnt = sd.cross_arms(dev(L[:, :, 0]), 0.02, 14)
-    assert np.array_equal(arms.cpu().numpy(), arms_o)
-    assert np.array_equal(cnt.cpu().numpy(), cnt_o)
+    sup = sd.cross_arms(dev(L[:, :, 0]), 0.02, 14)
+    assert np.array_equal(sd.support_arms(sup).cpu().numpy(), arms_o)
+    assert np.array_equal(sd.support_count(sup).cpu().numpy(), cnt_o)
     assert cnt_o.max() > 30, "test image must have non-trivial support regions"
     vl, vr = _rand_vol(rng, D, H, W), _rand_vol(rng, D, H, W)
     ol, orr = o.cost_volume_aggregation(L, R, vl, vr, 0.02, 14, 3)
@@ -362,11 +362,11 @@ def test_full_size_properties_cfg2(sd):
     assert torch.equal(sd.wta(v), torch.argmin(v, dim=0).float())
     # CBCA of a constant volume is that constant (averaging is a partition of unity) and is bounded by min/max
     img = (torch.rand((H, W), device="cuda", generator=g) * 4).round() / 4
-    arms, cnt = sd.cross_arms(img, 0.02, 14)
+    sup = sd.cross_arms(img, 0.02, 14)
     c = torch.full((4, H, W), -0.375, device="cuda")
-    res, _ = sd.cbca(c, torch.empty_like(c), arms, cnt, 3, 14)
+    res, _ = sd.cbca(c, torch.empty_like(c), sup, 3, 14)
     assert torch.equal(res, torch.full_like(res, -0.375))
-    res, _ = sd.cbca(v[:8].clone(), torch.empty((8, H, W), device="cuda"), arms, cnt, 2, 14)
+    res, _ = sd.cbca(v[:8].clone(), torch.empty((8, H, W), device="cuda"), sup, 2, 14)
     assert res.min() >= v[:8].min() - 1e-6 and res.max() <= v[:8].max() + 1e-6
     # SGM: adding a constant to the whole volume adds the same constant to the output of a pass (the recurrence adds
     # min(...) of the previous pixel and subtracts its min_k, which shift together) - checked on integer-valued

@@ -51,7 +51,7 @@ def main():
     va = -torch.rand((D, H, W), device="cuda", generator=g)
     vb = torch.empty_like(va)
     vol_bytes = 4.0 * D * H * W
-    arms, cnt = sd.cross_arms(dl, 0.02, 14)
+    sup = sd.cross_arms(dl, 0.02, 14)
     rows = []
 
     def add(name, fn, nbytes):
@@ -62,8 +62,8 @@ def main():
         rows.append((name, ms, gbs))
         print("%-22s %8.4f ms  %8.1f GB/s  %5.1f%% of HBM peak" % (name, ms, gbs, 100 * gbs / HBM_PEAK_GBS), flush=True)
 
-    add("cbca_iter", lambda: sd.cbca(va, vb, arms, cnt, 1, 14, hip.MCCNN_CBCA_SEPARABLE), 2 * vol_bytes)
-    add("cbca_iter_reforder", lambda: sd.cbca(va, vb, arms, cnt, 1, 14, hip.MCCNN_CBCA_REFERENCE_ORDER), 2 * vol_bytes)
+    add("cbca_iter", lambda: sd.cbca(va, vb, sup, 1, 14, hip.MCCNN_CBCA_SEPARABLE), 2 * vol_bytes)
+    add("cbca_iter_reforder", lambda: sd.cbca(va, vb, sup, 1, 14, hip.MCCNN_CBCA_REFERENCE_ORDER), 2 * vol_bytes)
     hwd = sd.dhw_to_hwd(va)
     hwd2 = sd.dhw_to_hwd(vb)
     scratch = sd.sgm_scratch(H, W, D, va.device)
