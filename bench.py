@@ -72,9 +72,9 @@ def main():
 
     import numpy as np
     import torch
-    import torch.distributed as dist
 
     import _hipabi as hip
+    import distributed as mgpu
     import stereo_device as sd
     import synthetic
     import tf_checkpoint
@@ -82,9 +82,7 @@ def main():
 
     hip.require_device()  # raises without a GPU or without the built library: no fallback
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    mgpu.init("nccl", torch.device("cuda", local_rank))   # RCCL; only the barrier + timing all_gather use it
 
     H, W, D = CONFIGS[args.config]
     wpath = os.path.join(ROOT, "tests", "golden", "mccnn_fast_weights.npz")
@@ -102,32 +100,21 @@ def main():
         net, cv_mode=hip.MCCNN_CV_EXACT if args.exact else hip.MCCNN_CV_MFMA,
         cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER if args.exact else hip.MCCNN_CBCA_SEPARABLE)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
     for _ in range(args.warmup):
         matcher.match(dl, dr, D)
     torch.cuda.synchronize()
-    barrier()
+    mgpu.barrier()
     timer = sd.StageTimer(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = matcher.match(dl, dr, D, timer=timer)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    barrier()
+    mgpu.barrier()
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        ts = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(ts, t)
-        elapsed_max = max(float(x.item()) for x in ts)
-    else:
-        elapsed_max = elapsed
+    elapsed_max = max(mgpu.gather_elapsed(elapsed))
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        mgpu.finalize()
         return
 
     voxels = H * W * D
@@ -173,8 +160,7 @@ def main():
     else:
         result["cpu_baseline"] = None
     print(json.dumps(result))
-    if world > 1:
-        dist.destroy_process_group()
+    mgpu.finalize()
 
 
 if __name__ == "__main__":

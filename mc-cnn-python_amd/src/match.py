@@ -72,12 +72,6 @@ def hyper_parameters(args):
                 sgm_V=args.sgm_V, blur_sigma=args.blur_sigma, blur_threshold=args.blur_threshold)
 
 
-def shard_indices(start, end, n_items, rank, world):
-    """Indices of the inclusive window [start, end] (clipped to the list) that belong to `rank` of `world`."""
-    last = min(end, n_items - 1)
-    return [i for i in range(max(start, 0), last + 1) if (i - max(start, 0)) % world == rank]
-
-
 def main(argv=None):
     args = parser.parse_args(argv)
 
@@ -117,6 +111,7 @@ def main(argv=None):
         cv_mode=hip.MCCNN_CV_EXACT if args.exact else hip.MCCNN_CV_MFMA,
         cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER if args.exact else hip.MCCNN_CBCA_SEPARABLE)
 
+    from distributed import shard_indices
     for index in shard_indices(args.start, args.end, len(img_paths), rank, world):
         left_path = img_paths[index].strip()
         print("index: {}".format(index))

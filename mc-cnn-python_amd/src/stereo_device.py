@@ -167,7 +167,7 @@ def sgm_average_hwd(image_left, image_right, vols_hwd, sides, D, sgm_P1, sgm_P2,
                     scratch, timer=_NO_TIMER):
     """SGM_average (pf:187-235) on HWD volumes: the four passes compose in place (the reference aliases one array,
     pf:544,568) and its '(a+b+c+d)/4.' of four aliases of that array is the identity in binary floating point
-    (oracle/mccnn_oracle.c evaluates it literally; the parity tests pin the equality)."""
+    (the CPU checker used by the tests evaluates it literally; the parity tests pin the equality)."""
     p1h = _f32(sgm_P1)
     p1v = _f32(sgm_P1 / sgm_V)  # Python double division, rounded once (pf:204)
     p2, q1, q2, thr = _f32(sgm_P2), _f32(sgm_Q1), _f32(sgm_Q2), _f32(sgm_D)

@@ -1,0 +1,92 @@
+"""CPU: the C-ABI shared library loads and exports exactly the symbols include/mccnn.h declares, the ctypes table in
+_hipabi.py matches it, and the product path refuses to run without a GPU (no CPU fallback, no oracle import)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mccnn.h")
+PKG = os.path.join(ROOT, "mc-cnn-python_amd")
+
+
+def header_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mccnn_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    import _hipabi
+    if not os.path.isfile(_hipabi.LIB_PATH):
+        subprocess.check_call(["make", "-C", PKG, "-j4"])   # hipcc cross-compiles gfx950 without a GPU
+    return _hipabi.LIB_PATH
+
+
+def test_header_declares_the_expected_stages():
+    fns = header_functions()
+    for stage in ("cost_volume", "cross_arms", "cbca_iter", "sgm_pass", "wta", "lr_status", "interpolate", "subpixel",
+                  "median", "bilateral", "dhw_to_hwd", "hwd_to_dhw", "l2norm_chw_to_hwc", "version",
+                  "last_error_string"):
+        assert "mccnn_" + stage in fns
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    lib = ctypes.CDLL(lib_path)
+    for name in header_functions():
+        assert hasattr(lib, name), "libmccnn_hip.so lacks %s declared in include/mccnn.h" % name
+    lib.mccnn_version.restype = ctypes.c_int
+    assert lib.mccnn_version() == 1
+    lib.mccnn_hwd_pitch.restype = ctypes.c_int
+    assert [lib.mccnn_hwd_pitch(d) for d in (1, 4, 5, 256, 400)] == [4, 4, 8, 256, 400]
+
+
+def test_ctypes_table_matches_header():
+    import _hipabi
+    assert sorted(_hipabi.SIGNATURES) == header_functions()
+
+
+def test_library_is_built_for_gfx950(lib_path):
+    out = subprocess.run(["strings", "-a", lib_path], capture_output=True, text=True).stdout
+    assert "gfx950" in out
+
+
+def test_argument_validation_without_gpu(lib_path):
+    """Entry points validate before they launch: error codes and messages, no crash, on a machine without a GPU."""
+    import _hipabi
+    lib = _hipabi.load()
+    assert lib.mccnn_wta(None, 4, 4, 4, None, None) == -1
+    assert b"null pointer" in lib.mccnn_last_error_string()
+    assert lib.mccnn_sgm_scratch_bytes(0, 10, 10) == 0
+    assert lib.mccnn_sgm_scratch_bytes(500, 750, 256) >= 2 * 500 * (750 + 2 * 256)
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible here")
+    import _hipabi
+    import numpy as np
+    import process_functional as pf
+    with pytest.raises(_hipabi.MccnnHipError):
+        _hipabi.require_device()
+    with pytest.raises(_hipabi.MccnnHipError):
+        pf.disparity_prediction(np.zeros((4, 5, 6), np.float32), np.zeros((4, 5, 6), np.float32))
+
+
+def test_product_never_imports_the_oracle():
+    """Nothing under mc-cnn-python_amd/ may import, link or execute oracle/ (it is test infrastructure)."""
+    bad = []
+    for dirpath, _dirs, files in os.walk(PKG):
+        if os.sep + "build" in dirpath or os.sep + "lib" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                if re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M) or "mccnn_oracle" in text \
+                        or "/oracle" in text:
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
