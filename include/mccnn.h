@@ -20,7 +20,7 @@
  *   features  [H][W][C]     float32, C = 64 (NET.features, NHWC)
  *   volume    "DHW" [D][H][W]   - the reference's layout; cost volume, CBCA, WTA, sub-pixel use it
  *             "HWD" [H][W][Dp]  - pixel-major, Dp = mccnn_hwd_pitch(D); the SGM scanline kernels use it
- *   support   [H][W]        8-byte records {uint8 up, down, left, right; int32 count} (mccnn_support_t)
+ *   support   [H][W]        uint32 words: four 5-bit cross-arm lengths + 12-bit region size (mccnn_support_t)
  *   maps      [H][W]        float32 disparity maps, int32 status / region counts
  */
 #ifndef MCCNN_H
@@ -60,13 +60,17 @@ int mccnn_cost_volume(const float *fl, const float *fr, int H, int W, int C, int
 
 /* ---- a3  compute_cross_region (pf:571-657) ----------------------------------------------------------------
  * Per pixel: the four arm lengths (<= L-1 per side, anchor-relative threshold |I(q)-I(p)| < tau) and the region
- * size count = sum over the vertical arm of (left+right+1), packed in one 8-byte record so that the aggregation
- * kernel fetches both with one load.  The reference's explicit coordinate list [H][W][(2L)^2][2] (padded with -1)
- * is produced by mccnn_cross_region_list for API compatibility only. */
-typedef struct mccnn_support {
-    uint8_t arm[4]; /* up, down, left, right - number of pixels accepted in that direction, self excluded */
-    int32_t count;  /* |U(p)|, the reference's union_region_num */
-} mccnn_support_t;  /* 8 bytes, plane layout [H][W] */
+ * size count = sum over the vertical arm of (left+right+1), packed in one 32-bit word so that the aggregation
+ * kernel fetches everything about two neighbouring pixels with one 8-byte load:
+ *     bits 0-4 up | 5-9 down | 10-14 left | 15-19 right | 20-31 count        (arms <= 31, count <= 63*63)
+ * hence L <= 32.  The reference's explicit coordinate list [H][W][(2L)^2][2] (padded with -1) is produced by
+ * mccnn_cross_region_list for API compatibility only. */
+typedef uint32_t mccnn_support_t; /* plane layout [H][W] */
+#define MCCNN_SUPPORT_UP(s) ((s) & 31u)
+#define MCCNN_SUPPORT_DOWN(s) (((s) >> 5) & 31u)
+#define MCCNN_SUPPORT_LEFT(s) (((s) >> 10) & 31u)
+#define MCCNN_SUPPORT_RIGHT(s) (((s) >> 15) & 31u)
+#define MCCNN_SUPPORT_COUNT(s) ((s) >> 20)
 int mccnn_cross_arms(const float *image, int H, int W, float tau, int L, mccnn_support_t *support,
                      mccnn_stream_t stream);
 int mccnn_cross_region_list(const mccnn_support_t *support, int H, int W, int L, int32_t *region,

@@ -2,29 +2,28 @@
 // a4 cost_volume_aggregation (pf:117-183) on gfx950.
 //
 // The reference materialises, per pixel, the coordinate list of its cross-shaped support region (int32
-// [H,W,784,2], 2.35 GB per image at 750x500) and then gathers through it.  Here a pixel carries one 8-byte record
-// (four uint8 arm lengths + the int32 region size, mccnn_support_t); the region is regenerated from the arms.
+// [H,W,784,2], 2.35 GB per image at 750x500) and then gathers through it.  Here a pixel carries
+// one packed 32-bit word (four 5-bit arm lengths + the 12-bit region size, mccnn_support_t); the region is
+// regenerated from the arms.
 //
 // Two aggregation kernels, same result set:
-//   cbca_stream_kernel  (MCCNN_CBCA_SEPARABLE, default distance) - O(1) work per output via float64 prefix sums,
-//                       one wavefront streams a column strip of one disparity plane; bound by the vector-memory
-//                       issue rate and HBM (8 B/voxel/iteration).
+//   cbca_pipe_kernel    (MCCNN_CBCA_SEPARABLE, default distance) - O(1) work per output via float64 prefix sums,
+//                       four wave-specialised stages stream a column strip of one disparity plane; bound by the
+//                       vector-memory issue rate and HBM (8 B/voxel/iteration).
 //   cbca_iter_kernel    LDS-tiled; REFERENCE_ORDER variant walks the region in the reference's list order and is
 //                       bit-exact; its separable variant serves distances > 14.
 #include "common.h"
 
 namespace mccnn {
 
-struct __attribute__((aligned(8))) Support {  // == mccnn_support_t
-    uint32_t arms;  // byte 0 up, 1 down, 2 left, 3 right
-    int32_t count;
-};
-static_assert(sizeof(Support) == 8 && sizeof(mccnn_support_t) == 8, "support record must be 8 bytes");
+typedef uint32_t Support;  // == mccnn_support_t: bits 0-4 up, 5-9 down, 10-14 left, 15-19 right, 20-31 region size
+static_assert(sizeof(mccnn_support_t) == 4, "support record must be 4 bytes");
 
-__device__ __forceinline__ int arm_up(uint32_t a) { return (int)(a & 0xff); }
-__device__ __forceinline__ int arm_down(uint32_t a) { return (int)((a >> 8) & 0xff); }
-__device__ __forceinline__ int arm_left(uint32_t a) { return (int)((a >> 16) & 0xff); }
-__device__ __forceinline__ int arm_right(uint32_t a) { return (int)(a >> 24); }
+__device__ __forceinline__ int arm_up(uint32_t a) { return (int)(a & 31u); }
+__device__ __forceinline__ int arm_down(uint32_t a) { return (int)((a >> 5) & 31u); }
+__device__ __forceinline__ int arm_left(uint32_t a) { return (int)((a >> 10) & 31u); }
+__device__ __forceinline__ int arm_right(uint32_t a) { return (int)((a >> 15) & 31u); }
+__device__ __forceinline__ int sup_count(uint32_t a) { return (int)(a >> 20); }
 
 // np.linalg.norm of the 1-vector (cur - other): sqrt(x*x), float32 (pf:588,596,615,623)
 __device__ __forceinline__ float norm1(float x)
@@ -66,22 +65,25 @@ __global__ __launch_bounds__(256) void cross_arms_kernel(const float *__restrict
             ++right;
         }
     }
-    sup[(size_t)h * W + w].arms = (uint32_t)up | ((uint32_t)down << 8) | ((uint32_t)left << 16) | ((uint32_t)right << 24);
+    sup[(size_t)h * W + w] = (uint32_t)up | ((uint32_t)down << 5) | ((uint32_t)left << 10) | ((uint32_t)right << 15);
 }
 
-// pf:640-653: region size = sum over the vertical arm of the horizontal arm sizes
+// pf:640-653: region size = sum over the vertical arm of the horizontal arm sizes.  The size goes into the upper 12
+// bits of the same word whose lower 20 bits (the arms, written by the previous kernel and never changed here) the
+// neighbours are reading: relaxed atomics make that formally race-free, and any mix of old/new words is correct.
 __global__ __launch_bounds__(256) void cross_count_kernel(Support *__restrict__ sup, int H, int W)
 {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     const int h = blockIdx.y;
     if (w >= W) return;
-    const uint32_t a = sup[(size_t)h * W + w].arms;
-    int n = 0;
+    auto ld = [&](size_t i) { return __hip_atomic_load(&sup[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    const uint32_t a = ld((size_t)h * W + w);
+    uint32_t n = 0;
     for (int q = h - arm_up(a); q <= h + arm_down(a); ++q) {
-        const uint32_t aq = sup[(size_t)q * W + w].arms;
+        const uint32_t aq = ld((size_t)q * W + w);
         n += arm_left(aq) + arm_right(aq) + 1;
     }
-    sup[(size_t)h * W + w].count = n;
+    __hip_atomic_fetch_or(&sup[(size_t)h * W + w], n << 20, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // pf:637-655: explicit list, order (self, up.., down..) x (self, left.., right..), padded with (-1,-1)
@@ -91,13 +93,13 @@ __global__ __launch_bounds__(256) void cross_region_list_kernel(const Support *_
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     const int h = blockIdx.y;
     if (w >= W) return;
-    const uint32_t a = sup[(size_t)h * W + w].arms;
+    const uint32_t a = sup[(size_t)h * W + w];
     int2 *r = reinterpret_cast<int2 *>(region) + ((size_t)h * W + w) * maxn;
     int n = 0;
     const int nu = arm_up(a), nv = 1 + nu + arm_down(a);
     for (int v = 0; v < nv; ++v) {
         const int q = v == 0 ? h : (v <= nu ? h - v : h + (v - nu));
-        const uint32_t aq = sup[(size_t)q * W + w].arms;
+        const uint32_t aq = sup[(size_t)q * W + w];
         const int nl = arm_left(aq), nh = 1 + nl + arm_right(aq);
         for (int z = 0; z < nh; ++z) {
             const int x = z == 0 ? w : (z <= nl ? w - z : w + (z - nl));
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void cbca_iter_kernel(const float *__restrict_
             const int hh = h0 - R + r, ww = w0 + c;
             float s = 0.f;
             if (hh >= 0 && hh < H && ww < W) {
-                const uint32_t a = sup[(size_t)hh * W + ww].arms;
+                const uint32_t a = sup[(size_t)hh * W + ww];
                 const float *row = &tin[r * IP + c + R];
                 for (int j = -arm_left(a); j <= arm_right(a); ++j) s += row[j];
             }
@@ -158,8 +160,8 @@ __global__ __launch_bounds__(256) void cbca_iter_kernel(const float *__restrict_
                 const Support sp = sup[(size_t)hh * W + ww];
                 const float *col = &ths[(r + R) * CB_TW + c];
                 float s = 0.f;
-                for (int i = -arm_up(sp.arms); i <= arm_down(sp.arms); ++i) s += col[i * CB_TW];
-                dst[(size_t)hh * W + ww] = s / (float)sp.count;  // pf:161
+                for (int i = -arm_up(sp); i <= arm_down(sp); ++i) s += col[i * CB_TW];
+                dst[(size_t)hh * W + ww] = s / (float)sup_count(sp);  // pf:161
             }
         }
     } else {
@@ -172,16 +174,16 @@ __global__ __launch_bounds__(256) void cbca_iter_kernel(const float *__restrict_
             if (hh < H && ww < W) {
                 const Support sp = sup[(size_t)hh * W + ww];
                 float s = 0.f;
-                const int nu = arm_up(sp.arms), nv = 1 + nu + arm_down(sp.arms);
+                const int nu = arm_up(sp), nv = 1 + nu + arm_down(sp);
                 for (int v = 0; v < nv; ++v) {
                     const int dq = v == 0 ? 0 : (v <= nu ? -v : v - nu);
-                    const uint32_t aq = sup[(size_t)(hh + dq) * W + ww].arms;
+                    const uint32_t aq = sup[(size_t)(hh + dq) * W + ww];
                     const float *row = &tin[(r + R + dq) * IP + c + R];
                     s += row[0];
                     for (int z = 1; z <= arm_left(aq); ++z) s += row[-z];
                     for (int z = 1; z <= arm_right(aq); ++z) s += row[z];
                 }
-                dst[(size_t)hh * W + ww] = s / (float)sp.count;
+                dst[(size_t)hh * W + ww] = s / (float)sup_count(sp);
             }
         }
     }
@@ -199,25 +201,34 @@ static int launch_cbca(const float *in, float *out, const Support *sup, int D, i
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Streaming separable aggregation with O(1) work per output, independent of the arm lengths.
+// Streaming separable aggregation: O(1) work per output, independent of the arm lengths (MCCNN_CBCA_SEPARABLE).
 //
-// The per-pixel loops above cost (wave-maximum arm length) dependent LDS round trips per output.  Here one
-// wavefront owns a strip of OUTW output columns of one disparity plane and walks down the rows:
+// The per-pixel loops of cbca_iter_kernel cost (wave-maximum arm length) dependent LDS round trips per output.  Here
+// a strip of OUTW = 100 output columns of one disparity plane is streamed down its rows:
 //   row y arrives (2 floats per lane, 128 columns = 100 outputs + 14/13-column halos)
 //     -> float64 inclusive prefix sum P along the row (DPP scan across the 64 lanes)
 //     -> horizontal-arm sum of pixel (y,c) = P[c+right] - P[c-left-1]              (2 LDS reads)
-//     -> running float64 column prefix Q[y][c] += that, kept in a 32-row LDS ring
+//     -> running float64 column prefix Q[y][c] += that, kept in an LDS ring
 //   row y-13 leaves: vertical-arm sum = Q[y'+down] - Q[y'-up-1], times 1/|U|, rounded once to float32.
 // float64 differences of prefix sums of float32 data carry ~1e-14 absolute error, so the result is the correctly
 // rounded region mean; it differs from the reference's sequential float32 sum only by that sum's own rounding
-// (same tolerance as any separable order).  Lanes never diverge and no barrier is needed between waves: every
-// workgroup is a single wavefront with a private LDS image (LDS operations of one wave execute in order).
+// (same tolerance as any separable order).  Lanes never diverge.
 //
-// Memory side: the vector-memory (TA) pipe costs ~16 cycles per wave instruction whatever its width, so each row
-// moves with 4 instructions: one dwordx2 (2 floats), two dwordx4 (support records of the staged and of the emitted
-// row, 2 pixels each), one dwordx2 store - all raw buffer ops: per-lane byte offset + wave-uniform row offset, no
-// address arithmetic, hardware range check instead of clamping (out-of-image columns read finite neighbours or 0;
-// no arm can reach them, so they cancel in the prefix differences).
+// Wave specialisation.  A single wave per strip is bound by its own serial instruction chain (the float64 ring caps a
+// CU at ~5 such strips; measured 0.53-0.80 ms per iteration at 750x500x256).  So FOUR waves share one strip (one
+// ring) and each runs one stage of the row pipeline in lock step, one barrier per batch of B = 4 rows:
+//     iteration t:   waves 0,3  scan   batch t     (2 rows each)  -> prow[t & 1]
+//                    wave  1    hsum   batch t-1   prow lookups, column prefix -> ring rows
+//                    wave  2    emit   batch t-2   ring lookups, x 1/|U|, store
+// 16 waves per CU, and a strip advances at the pace of its slowest stage instead of the sum of all three.
+//
+// Memory side.  The vector-memory (TA) pipe is what this kernel saturates (TA busy 72 % with 8-byte support records),
+// so each row moves with four 8-byte-per-lane instructions: the 2 floats, the packed support words of the staged row
+// and of the emitted row (2 pixels each), and the 2-float store - all raw buffer ops: per-lane byte offset +
+// wave-uniform row offset, no address arithmetic.  Every access stays inside its plane by construction (the buffer range
+// check does not cover the scalar row offset): pairs entirely outside the image are clamped onto valid columns - no arm
+// can reach those elements, so any finite value cancels in the prefix differences - and the one pair that can straddle
+// the right edge (odd W) is fetched one column early and swizzled.
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ double dpp_f64(double x)
 {
@@ -226,39 +237,40 @@ __device__ __forceinline__ double dpp_f64(double x)
     return __hiloint2double(hi, lo);
 }
 
-// 1/n for the region sizes n <= (2*14)^2, rounded to float64 at compile time (the emit stage multiplies the float64
-// region sum by it and rounds once to float32: the correctly rounded quotient up to ~1e-8 of near-ties)
+// 1/n for the region sizes n <= 63*63, rounded to float64 at compile time: the emit stage gathers it (the 32 KB table
+// stays cache resident) instead of spending ~40 VALU cycles per output on a float64 reciprocal, multiplies the float64
+// region sum by it and rounds once to float32 - the correctly rounded quotient up to ~1e-8 of near-ties.
 struct InvTable {
-    double v[800];
+    double v[4096];
     constexpr InvTable() : v()
     {
         v[0] = 0.0;
-        for (int i = 1; i < 800; ++i) v[i] = 1.0 / (double)i;
+        for (int i = 1; i < 4096; ++i) v[i] = 1.0 / (double)i;
     }
 };
 __device__ const InvTable kInv = InvTable();
 
-constexpr int CS_IN = 128;  // staged columns per wave (2 per lane)
+constexpr int CS_IN = 128;  // staged columns per strip (2 per lane)
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <int R, int RING>
-__global__ __launch_bounds__(64) void cbca_stream_kernel(const float *__restrict__ in, float *__restrict__ out,
-                                                         const Support *__restrict__ sup, int H, int W, int rows,
-                                                         int nstrips, int nchunks, int total)
+template <int R, int RING, bool ODDW>
+__global__ __launch_bounds__(256) void cbca_pipe_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                        const Support *__restrict__ sup, int H, int W, int rows,
+                                                        int nstrips, int nchunks, int total)
 {
     constexpr int RS = (R + 1) & ~1;           // staged halo on the left, even so that lanes own aligned column pairs
-    constexpr int OUTW = (CS_IN - RS - R) & ~1; // output columns per wave
+    constexpr int OUTW = (CS_IN - RS - R) & ~1; // output columns per strip
     constexpr int RP = (OUTW + 3) & ~1;        // ring pitch in doubles (even, > OUTW)
-    constexpr int B = 4;                       // rows advanced together (independent chains -> ILP, 1 sync per stage)
-    constexpr int NB = 3;                      // batches of row registers: loads run 2 batches (8 rows) ahead
+    constexpr int B = 4;                       // rows per batch
+    constexpr int NPF = 4;                     // batches of loads each role keeps in flight
     constexpr int PRP = CS_IN + 2;             // prow pitch: prow[k+1] = sum of staged elements 0..k, prow[0] = 0
-    static_assert(RING >= 2 * R + 2 + B && (RING & (RING - 1)) == 0, "ring must cover up+1+down rows of a batch");
-    static_assert((2 * R + 2) * (2 * R + 2) <= 800, "reciprocal table too small");
-    static_assert((OUTW & 1) == 0, "lanes own column pairs");
-    __shared__ double prow[B * PRP];
+    // emit(t-2) reads logical rows [y0-2R-1, y0+B-1] of the ring while hsum(t-1) writes the next B rows: 2R+1+2B rows
+    // must not alias (a power-of-two ring would need 64 rows = 52 KB; 36 rows keep 4 workgroups per CU)
+    static_assert(RING >= 2 * R + 1 + 2 * B, "ring must hold the emit window plus the batch being written");
+    __shared__ double prow[2 * B * PRP];       // double-buffered by batch parity
     __shared__ double ring[RING * RP];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform role id
     // XCD-aware order: consecutive work items (neighbouring strips of one plane share halo columns) stay on one
     // XCD's L2; the dispatcher places block b on XCD b % 8 (speed only, any placement is correct)
     int id;
@@ -271,6 +283,8 @@ __global__ __launch_bounds__(64) void cbca_stream_kernel(const float *__restrict
     const int d = id / (nstrips * nchunks);
     const int w0 = strip * OUTW, h0 = chunk * rows, h1 = min(h0 + rows, H);
     const int ys = max(h0 - R, 0), ye = min(h1 - 1 + R, H - 1);
+    const int ylast = h1 - 1 + R;
+    const int nb = (ylast - ys + B) / B;       // batches; batch k holds rows ys + k*B + (0..B-1)
     const size_t plane = (size_t)H * W;
 
     const int x0 = w0 - RS + 2 * lane;         // image column of this lane's first staged element (even)
@@ -278,156 +292,209 @@ __global__ __launch_bounds__(64) void cbca_stream_kernel(const float *__restrict
     const bool oc0 = 2 * lane < OUTW && c0 < W, oc1 = 2 * lane + 1 < OUTW && c0 + 1 < W;
     const int i0 = oc0 ? RS + 2 * lane : RS;   // staged index of output column c0 (idle lanes stay in bounds)
     const bool rl = 2 * lane < RP;             // lane owns two ring columns
-    // Every access stays inside its plane by construction (the buffer range check does not cover the scalar row
-    // offset): pairs entirely outside the image are clamped onto valid columns - no arm can reach those elements, so
-    // any finite value cancels in the prefix differences - and the one pair that can straddle the right edge (odd W)
-    // is fetched one column early and swizzled.
-    const bool vstr = x0 == W - 1, sstr = c0 == W - 1;
+    const bool vstr = ODDW && x0 == W - 1, sstr = ODDW && c0 == W - 1;
     const int x0c = vstr ? W - 2 : min(max(x0, 0), W - 2);
     const int c0c = sstr ? W - 2 : min(c0, W - 2);
-
-    // buffer descriptors (wave-uniform); voffset = per-lane byte offset, soffset = wave-uniform row offset
     const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(in + (size_t)d * plane), 0, (int)(plane * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_dst =
         __builtin_amdgcn_make_buffer_rsrc(out + (size_t)d * plane, 0, (int)(plane * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_sup =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<Support *>(sup), 0, (int)(plane * 8), 0x00020000);
-    const int vb = 4 * x0c, sb = 8 * c0c, ob = 4 * c0;
-    const int rowv = 4 * W, rows8 = 8 * W;
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<Support *>(sup), 0, (int)(plane * 4), 0x00020000);
+    const int vb = 4 * x0c, sb = 4 * c0c, ob = 4 * c0;
+    const int rowv = 4 * W;
 
-    if (lane < B) prow[lane * PRP] = 0.0;
-    if (rl) {                                  // Q of the row above the first staged row is zero
-        double *z = &ring[((ys - 1) & (RING - 1)) * RP + 2 * lane];
+    if (threadIdx.x < 2 * B) prow[threadIdx.x * PRP] = 0.0;
+    if (wave == 1 && rl) {                     // Q of the row above the first staged row is zero
+        double *z = &ring[((ys - 1 + RING) % RING) * RP + 2 * lane];
         z[0] = 0.0;
         z[1] = 0.0;
     }
-    double q0 = 0.0, q1 = 0.0;
 
-    u32x2 vv[NB * B];                          // two staged floats
-    u32x4 sy[NB * B];                          // support records of the staged row (left/right used)
-    u32x4 so[NB * B];                          // support records of the emitted row (up/down/count used)
-    auto issue = [&](int slot, int y) {
-        const int yr = min(y, ye);                          // wave-uniform
-        const int yo = min(max(y - R, h0), h1 - 1);         // wave-uniform
-        vv[slot] = __builtin_amdgcn_raw_buffer_load_b64(rs_src, vb, yr * rowv, 0);
-        sy[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_sup, sb, yr * rows8, 0);
-        so[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_sup, sb, yo * rows8, 0);
-    };
-    const int ylast = h1 - 1 + R;
+    if (wave == 0 || wave == 3) {
+        // ---------------- scan role: rows b0, b0+1 of every batch ----------------
+        const int b0 = wave == 0 ? 0 : 2;
+        u32x2 vv[NPF][2];
+        auto issue = [&](int slot, int k) {
 #pragma unroll
-    for (int k = 0; k < NB * B; ++k) issue(k, ys + k);
-
-    for (int yb = ys; yb <= ylast; yb += NB * B) {
+            for (int j = 0; j < 2; ++j)
+                vv[slot][j] = __builtin_amdgcn_raw_buffer_load_b64(rs_src, vb, min(ys + k * B + b0 + j, ye) * rowv, 0);
+        };
 #pragma unroll
-        for (int g = 0; g < NB; ++g) {
-            const int y0 = yb + g * B;
-            if (y0 > ylast) break;
-            // reciprocal region sizes of the rows emitted by this batch (consumed two LDS stages from now)
-            double rn0[B], rn1[B];
+        for (int k = 0; k < NPF; ++k) issue(k, k);
+        for (int tb = 0; tb < nb + 2; tb += NPF) {
 #pragma unroll
-            for (int b = 0; b < B; ++b) {
-                rn0[b] = kInv.v[sstr ? so[g * B + b].w : so[g * B + b].y];
-                rn1[b] = kInv.v[so[g * B + b].w];
-            }
-            // stage 1: B independent float64 row scans -> prow (steps outermost so the B chains interleave)
-            {
-                double a0[B], t[B], ex[B];
+            for (int u = 0; u < NPF; ++u) {
+                const int t = tb + u;
+                if (t >= nb + 2) break;
+                if (t < nb) {
+                    double a0[2], tt[2], ex[2];
 #pragma unroll
-                for (int b = 0; b < B; ++b) {
-                    a0[b] = (double)__uint_as_float(vstr ? vv[g * B + b].y : vv[g * B + b].x);
-                    t[b] = a0[b] + (double)__uint_as_float(vv[g * B + b].y);
-                }
-#pragma unroll
-                for (int b = 0; b < B; ++b) t[b] += dpp_f64<0x111>(t[b]);        // row_shr:1
-#pragma unroll
-                for (int b = 0; b < B; ++b) t[b] += dpp_f64<0x112>(t[b]);        // row_shr:2
-#pragma unroll
-                for (int b = 0; b < B; ++b) t[b] += dpp_f64<0x114>(t[b]);        // row_shr:4
-#pragma unroll
-                for (int b = 0; b < B; ++b) t[b] += dpp_f64<0x118>(t[b]);        // row_shr:8
-#pragma unroll
-                for (int b = 0; b < B; ++b) t[b] += dpp_f64<0x142, 0xA>(t[b]);   // row_bcast:15
-#pragma unroll
-                for (int b = 0; b < B; ++b) t[b] += dpp_f64<0x143, 0xC>(t[b]);   // row_bcast:31
-#pragma unroll
-                for (int b = 0; b < B; ++b) ex[b] = dpp_f64<0x138>(t[b]);        // wave_shr:1 -> exclusive
-#pragma unroll
-                for (int b = 0; b < B; ++b) {
-                    double2 pp;
-                    pp.x = ex[b] + a0[b];
-                    pp.y = t[b];
-                    *reinterpret_cast<double2 *>(&prow[b * PRP + 1 + 2 * lane]) = pp;
-                }
-            }
-            __syncthreads();  // single-wave workgroup: orders the LDS writes above before the reads below
-            // stage 2: horizontal-arm sums, running column prefix, ring rows
-            double hs0[B], hs1[B];
-#pragma unroll
-            for (int b = 0; b < B; ++b) {
-                const uint32_t a = sstr ? sy[g * B + b].z : sy[g * B + b].x, c = sy[g * B + b].z;
-                const double *pr = &prow[b * PRP];
-                // sum over staged elements [i-left, i+right] = prow[i+right+1] - prow[i-left]
-                hs0[b] = pr[i0 + arm_right(a) + 1] - pr[i0 - arm_left(a)];
-                hs1[b] = pr[i0 + 1 + arm_right(c) + 1] - pr[i0 + 1 - arm_left(c)];
-            }
-#pragma unroll
-            for (int b = 0; b < B; ++b) {
-                const int y = y0 + b;
-                if (y <= ye) {                 // rows past the image bottom are never referenced
-                    q0 += hs0[b];
-                    q1 += hs1[b];
-                    if (rl) {
-                        double2 qq;
-                        qq.x = q0;
-                        qq.y = q1;
-                        *reinterpret_cast<double2 *>(&ring[(y & (RING - 1)) * RP + 2 * lane]) = qq;
+                    for (int j = 0; j < 2; ++j) {
+                        a0[j] = (double)__uint_as_float(vstr ? vv[u][j].y : vv[u][j].x);
+                        tt[j] = a0[j] + (double)__uint_as_float(vv[u][j].y);
                     }
+                    // steps outermost so the two rows' dependent chains interleave
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) tt[j] += dpp_f64<0x111>(tt[j]);        // row_shr:1
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) tt[j] += dpp_f64<0x112>(tt[j]);        // row_shr:2
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) tt[j] += dpp_f64<0x114>(tt[j]);        // row_shr:4
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) tt[j] += dpp_f64<0x118>(tt[j]);        // row_shr:8
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) tt[j] += dpp_f64<0x142, 0xA>(tt[j]);   // row_bcast:15
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) tt[j] += dpp_f64<0x143, 0xC>(tt[j]);   // row_bcast:31
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) ex[j] = dpp_f64<0x138>(tt[j]);         // wave_shr:1 -> exclusive
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        double2 pp;
+                        pp.x = ex[j] + a0[j];
+                        pp.y = tt[j];
+                        *reinterpret_cast<double2 *>(&prow[((t & 1) * B + b0 + j) * PRP + 1 + 2 * lane]) = pp;
+                    }
+                    issue(u, t + NPF);
                 }
+                __syncthreads();
             }
-            __syncthreads();
-            // stage 3: emit rows y-R: vertical-arm sums from the ring, times 1/region size, one rounding to float32
+        }
+    } else if (wave == 1) {
+        // ---------------- hsum role: batch t-1 ----------------
+        double q0 = 0.0, q1 = 0.0;
+        u32x2 sy[NPF][B];
+        auto issue = [&](int slot, int k) {
+#pragma unroll
+            for (int b = 0; b < B; ++b)
+                sy[slot][b] = __builtin_amdgcn_raw_buffer_load_b64(rs_sup, sb, min(ys + k * B + b, ye) * rowv, 0);
+        };
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) issue(k, k);
+        for (int tb = 0; tb < nb + 2; tb += NPF) {
+#pragma unroll
+            for (int u = 0; u < NPF; ++u) {
+                const int t = tb + u;
+                if (t >= nb + 2) break;
+                const int k = t - 1;
+                const int slot = (u + NPF - 1) % NPF;
+                if (k >= 0 && k < nb) {
+                    double hs0[B], hs1[B];
+#pragma unroll
+                    for (int b = 0; b < B; ++b) {
+                        const uint32_t a = sstr ? sy[slot][b].y : sy[slot][b].x, c = sy[slot][b].y;
+                        const double *pr = &prow[((k & 1) * B + b) * PRP];
+                        // sum over staged elements [i-left, i+right] = prow[i+right+1] - prow[i-left]
+                        hs0[b] = pr[i0 + arm_right(a) + 1] - pr[i0 - arm_left(a)];
+                        hs1[b] = pr[i0 + 1 + arm_right(c) + 1] - pr[i0 + 1 - arm_left(c)];
+                    }
+#pragma unroll
+                    for (int b = 0; b < B; ++b) {
+                        const int y = ys + k * B + b;
+                        if (y <= ye) {         // rows past the image bottom are never referenced
+                            q0 += hs0[b];
+                            q1 += hs1[b];
+                            if (rl) {
+                                double2 qq;
+                                qq.x = q0;
+                                qq.y = q1;
+                                *reinterpret_cast<double2 *>(&ring[(y % RING) * RP + 2 * lane]) = qq;
+                            }
+                        }
+                    }
+                    issue(slot, k + NPF);
+                }
+                __syncthreads();
+            }
+        }
+    } else {
+        // ---------------- emit role: batch t-2 ----------------
+        u32x2 so[NPF][B];
+        double rn0[NPF][B], rn1[NPF][B];
+        auto issue = [&](int slot, int k) {
+#pragma unroll
+            for (int b = 0; b < B; ++b)
+                so[slot][b] = __builtin_amdgcn_raw_buffer_load_b64(
+                    rs_sup, sb, min(max(ys + k * B + b - R, h0), h1 - 1) * rowv, 0);
+        };
+        auto recip = [&](int slot) {   // gathers 1/|U| for the rows of a batch whose support words have landed
 #pragma unroll
             for (int b = 0; b < B; ++b) {
-                const int yo = y0 + b - R;
-                if (yo >= h0 && yo < h1) {
-                    const uint32_t a = sstr ? so[g * B + b].z : so[g * B + b].x, c = so[g * B + b].z;
-                    const int col = 2 * lane;
-                    const double s0 = ring[((yo + arm_down(a)) & (RING - 1)) * RP + col] -
-                                      ring[((yo - arm_up(a) - 1) & (RING - 1)) * RP + col];
-                    const double s1 = ring[((yo + arm_down(c)) & (RING - 1)) * RP + col + 1] -
-                                      ring[((yo - arm_up(c) - 1) & (RING - 1)) * RP + col + 1];
-                    u32x2 o;
-                    o.x = __float_as_uint((float)(s0 * rn0[b]));
-                    o.y = __float_as_uint((float)(s1 * rn1[b]));
-                    if (oc1)
-                        __builtin_amdgcn_raw_buffer_store_b64(o, rs_dst, ob, yo * rowv, 0);
-                    else if (oc0)
-                        __builtin_amdgcn_raw_buffer_store_b32(o.x, rs_dst, ob, yo * rowv, 0);
-                }
+                rn0[slot][b] = kInv.v[(sstr ? so[slot][b].y : so[slot][b].x) >> 20];
+                rn1[slot][b] = kInv.v[so[slot][b].y >> 20];
             }
-            __syncthreads();  // the next batch overwrites prow and advances the ring
+        };
 #pragma unroll
-            for (int b = 0; b < B; ++b) issue(g * B + b, y0 + b + NB * B);
+        for (int k = 0; k < NPF; ++k) issue(k, k);
+        recip(0);
+        for (int tb = 0; tb < nb + 2; tb += NPF) {
+#pragma unroll
+            for (int u = 0; u < NPF; ++u) {
+                const int t = tb + u;
+                if (t >= nb + 2) break;
+                const int k = t - 2;
+                const int slot = (u + NPF - 2) % NPF;
+                if (k >= 0 && k < nb) {
+                    recip((slot + 1) % NPF);   // next batch's reciprocals, one iteration ahead of their use
+#pragma unroll
+                    for (int b = 0; b < B; ++b) {
+                        const int yo = ys + k * B + b - R;
+                        if (yo >= h0 && yo < h1) {
+                            const uint32_t a = sstr ? so[slot][b].y : so[slot][b].x, c = so[slot][b].y;
+                            const int col = 2 * lane;
+                            const int ym = yo % RING;   // wave-uniform; per-lane wrap by unsigned min
+                            auto below = [&](int up) {
+                                const int i = ym - up - 1;
+                                return (int)min((unsigned)i, (unsigned)(i + RING));
+                            };
+                            auto above = [&](int dn) {
+                                const int i = ym + dn;
+                                return (int)min((unsigned)i, (unsigned)(i - RING));
+                            };
+                            const double s0 = ring[above(arm_down(a)) * RP + col] - ring[below(arm_up(a)) * RP + col];
+                            const double s1 =
+                                ring[above(arm_down(c)) * RP + col + 1] - ring[below(arm_up(c)) * RP + col + 1];
+                            u32x2 o;
+                            o.x = __float_as_uint((float)(s0 * rn0[slot][b]));
+                            o.y = __float_as_uint((float)(s1 * rn1[slot][b]));
+                            if (oc1)
+                                __builtin_amdgcn_raw_buffer_store_b64(o, rs_dst, ob, yo * rowv, 0);
+                            else if (oc0)
+                                __builtin_amdgcn_raw_buffer_store_b32(o.x, rs_dst, ob, yo * rowv, 0);
+                        }
+                    }
+                    issue(slot, k + NPF);
+                }
+                __syncthreads();
+            }
         }
     }
 }
 
 template <int R, int RING>
-static int launch_cbca_stream(const float *in, float *out, const Support *sup, int D, int H, int W, hipStream_t s)
+static int launch_cbca_pipe(const float *in, float *out, const Support *sup, int D, int H, int W, hipStream_t s)
 {
     constexpr int OUTW = (CS_IN - ((R + 1) & ~1) - R) & ~1;
     MCCNN_REQUIRE(W >= 2, MCCNN_E_UNSUPPORTED, "mccnn_cbca_iter: W=%d < 2", W);
     const int nstrips = cdiv(W, OUTW);
-    // row chunks of ~128 rows: each chunk re-reads 2R halo rows, so taller is cheaper; more chunks = more waves
-    const int nchunks = H > 192 ? cdiv(H, 128) : 1;
+    // row chunks of ~128 rows: each chunk re-reads 2R halo rows, so taller is cheaper; more chunks = more workgroups
+    // Row chunks: every chunk re-stages 2R halo rows, so chunks are as tall as the launch allows while still giving
+    // the 256 CUs x 4 resident workgroups about two rounds of work (measured at 750x500x256: 4 chunks 0.40 ms,
+    // 2 chunks 0.37 ms, 1 chunk 0.35 ms); never shorter than 64 rows.
+    const int want = cdiv(2048, (long)nstrips * D);
+    const int nchunks = max(1, min(want, H / 64));
     const int rows = cdiv(H, nchunks);
     const long total = (long)nstrips * nchunks * D;
-    MCCNN_REQUIRE(total <= 0x7fffffffL && (long)H * W * 8 <= 0x7fffffffL, MCCNN_E_UNSUPPORTED,
+    MCCNN_REQUIRE(total <= 0x7fffffffL && (long)H * W * 4 <= 0x7fffffffL, MCCNN_E_UNSUPPORTED,
                   "mccnn_cbca_iter: image %dx%d / volume too large for 32-bit buffer offsets", W, H);
-    hipLaunchKernelGGL((cbca_stream_kernel<R, RING>), dim3((unsigned)total), dim3(64), 0, s, in, out, sup, H, W, rows,
-                       nstrips, nchunks, (int)total);
-    return check_launch("mccnn_cbca_iter(stream)");
+    if (W & 1)
+        hipLaunchKernelGGL((cbca_pipe_kernel<R, RING, true>), dim3((unsigned)total), dim3(256), 0, s, in, out, sup, H,
+                           W, rows, nstrips, nchunks, (int)total);
+    else
+        hipLaunchKernelGGL((cbca_pipe_kernel<R, RING, false>), dim3((unsigned)total), dim3(256), 0, s, in, out, sup, H,
+                           W, rows, nstrips, nchunks, (int)total);
+    return check_launch("mccnn_cbca_iter(pipe)");
 }
 
 }  // namespace mccnn
@@ -438,14 +505,14 @@ extern "C" int mccnn_cross_arms(const float *image, int H, int W, float tau, int
     using namespace mccnn;
     MCCNN_REQUIRE(image && support, MCCNN_E_INVALID, "mccnn_cross_arms: null pointer");
     MCCNN_REQUIRE(H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_cross_arms: non-positive size");
-    MCCNN_REQUIRE(L >= 1 && L <= 128, MCCNN_E_UNSUPPORTED, "mccnn_cross_arms: L=%d outside [1,128] (uint8 arms)", L);
+    MCCNN_REQUIRE(L >= 1 && L <= 32, MCCNN_E_UNSUPPORTED,
+                  "mccnn_cross_arms: L=%d outside [1,32] (5-bit arms, 12-bit region size)", L);
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(cdiv(W, 256), H), block(256);
-    Support *sup = reinterpret_cast<Support *>(support);
-    hipLaunchKernelGGL(cross_arms_kernel, grid, block, 0, s, image, H, W, tau, L, sup);
+    hipLaunchKernelGGL(cross_arms_kernel, grid, block, 0, s, image, H, W, tau, L, support);
     int rc = check_launch("mccnn_cross_arms");
     if (rc) return rc;
-    hipLaunchKernelGGL(cross_count_kernel, grid, block, 0, s, sup, H, W);
+    hipLaunchKernelGGL(cross_count_kernel, grid, block, 0, s, support, H, W);
     return check_launch("mccnn_cross_arms(count)");
 }
 
@@ -456,8 +523,8 @@ extern "C" int mccnn_cross_region_list(const mccnn_support_t *support, int H, in
     MCCNN_REQUIRE(support && region, MCCNN_E_INVALID, "mccnn_cross_region_list: null pointer");
     MCCNN_REQUIRE(H > 0 && W > 0 && L >= 1, MCCNN_E_INVALID, "mccnn_cross_region_list: bad size");
     const dim3 grid(cdiv(W, 256), H), block(256);
-    hipLaunchKernelGGL(cross_region_list_kernel, grid, block, 0, (hipStream_t)stream,
-                       reinterpret_cast<const Support *>(support), H, W, (2 * L) * (2 * L), region);
+    hipLaunchKernelGGL(cross_region_list_kernel, grid, block, 0, (hipStream_t)stream, support, H, W, (2 * L) * (2 * L),
+                       region);
     return check_launch("mccnn_cross_region_list");
 }
 
@@ -472,9 +539,8 @@ extern "C" int mccnn_cbca_iter(const float *in, float *out, const mccnn_support_
     MCCNN_REQUIRE(order == MCCNN_CBCA_SEPARABLE || order == MCCNN_CBCA_REFERENCE_ORDER, MCCNN_E_INVALID,
                   "mccnn_cbca_iter: unknown order %d", order);
     hipStream_t s = (hipStream_t)stream;
-    const Support *sup = reinterpret_cast<const Support *>(support);
-    if (order == MCCNN_CBCA_SEPARABLE && L <= 14) return launch_cbca_stream<13, 32>(in, out, sup, D, H, W, s);
-    if (L <= 14) return launch_cbca<13, 32>(in, out, sup, D, H, W, order, s);
-    if (L <= 32) return launch_cbca<31, 16>(in, out, sup, D, H, W, order, s);
+    if (order == MCCNN_CBCA_SEPARABLE && L <= 14) return launch_cbca_pipe<13, 36>(in, out, support, D, H, W, s);
+    if (L <= 14) return launch_cbca<13, 32>(in, out, support, D, H, W, order, s);
+    if (L <= 32) return launch_cbca<31, 16>(in, out, support, D, H, W, order, s);
     MCCNN_REQUIRE(false, MCCNN_E_UNSUPPORTED, "mccnn_cbca_iter: L=%d > 32 not built", L);
 }

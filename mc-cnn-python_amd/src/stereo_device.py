@@ -77,27 +77,28 @@ def cost_volume(fl, fr, ndisp, mode=hip.MCCNN_CV_EXACT, out=None):
 
 # ---- a3 ----------------------------------------------------------------------------------------------------------
 def cross_arms(image, intensity_threshold, distance_threshold):
-    """image [H,W] -> support plane, int32 [H,W,2]: word 0 = four uint8 arm lengths (up, down, left, right), word 1 =
-    region size (mccnn_support_t).  support_arms()/support_count() give the two parts as separate views."""
+    """image [H,W] -> support plane, int32 [H,W]: one packed word per pixel (mccnn_support_t: bits 0-4 up, 5-9 down,
+    10-14 left, 15-19 right, 20-31 region size).  support_arms()/support_count() decode it."""
     H, W = image.shape
-    support = torch.empty((H, W, 2), dtype=torch.int32, device=image.device)
+    support = torch.empty((H, W), dtype=torch.int32, device=image.device)
     hip.check(hip.load().mccnn_cross_arms(hip.ptr(image), H, W, _f32(intensity_threshold), int(distance_threshold),
                                           hip.ptr(support), hip.stream()), "mccnn_cross_arms")
     return support
 
 
 def support_arms(support):
-    """uint8 [H,W,4] view: up, down, left, right."""
-    return support.view(torch.uint8)[:, :, :4]
+    """uint8 [H,W,4]: up, down, left, right."""
+    s = support.to(torch.int64) & 0xFFFFFFFF
+    return torch.stack([(s >> sh) & 31 for sh in (0, 5, 10, 15)], dim=-1).to(torch.uint8)
 
 
 def support_count(support):
-    """int32 [H,W] view of the region sizes (the reference's union_region_num)."""
-    return support[:, :, 1]
+    """int32 [H,W] region sizes (the reference's union_region_num)."""
+    return (((support.to(torch.int64) & 0xFFFFFFFF) >> 20) & 0xFFF).to(torch.int32)
 
 
 def cross_region_list(support, distance_threshold):
-    H, W, _ = support.shape
+    H, W = support.shape
     L = int(distance_threshold)
     region = torch.empty((H, W, (2 * L) ** 2, 2), dtype=torch.int32, device=support.device)
     hip.check(hip.load().mccnn_cross_region_list(hip.ptr(support), H, W, L, hip.ptr(region), hip.stream()),
