@@ -220,7 +220,8 @@ static int launch_cbca(const float *in, float *out, const Support *sup, int D, i
 //     iteration t:   waves 0,3  scan   batch t     (2 rows each)  -> prow[t & 1]
 //                    wave  1    hsum   batch t-1   prow lookups, column prefix -> ring rows
 //                    wave  2    emit   batch t-2   ring lookups, x 1/|U|, store
-// 16 waves per CU, and a strip advances at the pace of its slowest stage instead of the sum of all three.
+// 16 waves per CU, and a strip advances at the pace of its slowest stage instead of the sum of all three (measured
+// alone at 750x500x256: scan 0.14 ms, hsum 0.16 ms, emit 0.28 ms; a fifth wave sharing the emit rows was slower).
 //
 // Memory side.  The vector-memory (TA) pipe is what this kernel saturates (TA busy 72 % with 8-byte support records),
 // so each row moves with four 8-byte-per-lane instructions: the 2 floats, the packed support words of the staged row
@@ -381,26 +382,37 @@ __global__ __launch_bounds__(256) void cbca_pipe_kernel(const float *__restrict_
                 const int slot = (u + NPF - 1) % NPF;
                 if (k >= 0 && k < nb) {
                     double hs0[B], hs1[B];
+                    {
+                        double pa0[B], pb0[B], pa1[B], pb1[B];   // all 16 prow reads in flight before the first use
+                        const char *prb = reinterpret_cast<const char *>(prow) + (k & 1) * (B * PRP * 8);
 #pragma unroll
-                    for (int b = 0; b < B; ++b) {
-                        const uint32_t a = sstr ? sy[slot][b].y : sy[slot][b].x, c = sy[slot][b].y;
-                        const double *pr = &prow[((k & 1) * B + b) * PRP];
-                        // sum over staged elements [i-left, i+right] = prow[i+right+1] - prow[i-left]
-                        hs0[b] = pr[i0 + arm_right(a) + 1] - pr[i0 - arm_left(a)];
-                        hs1[b] = pr[i0 + 1 + arm_right(c) + 1] - pr[i0 + 1 - arm_left(c)];
+                        for (int b = 0; b < B; ++b) {
+                            const uint32_t a = sstr ? sy[slot][b].y : sy[slot][b].x, c = sy[slot][b].y;
+                            const char *pr = prb + b * (PRP * 8) + 8 * i0;
+                            // sum over staged elements [i-left, i+right] = prow[i+right+1] - prow[i-left]
+                            pa0[b] = *reinterpret_cast<const double *>(pr + 8 * (arm_right(a) + 1));
+                            pb0[b] = *reinterpret_cast<const double *>(pr - 8 * arm_left(a));
+                            pa1[b] = *reinterpret_cast<const double *>(pr + 8 * (arm_right(c) + 2));
+                            pb1[b] = *reinterpret_cast<const double *>(pr + 8 - 8 * arm_left(c));
+                        }
+#pragma unroll
+                        for (int b = 0; b < B; ++b) {
+                            hs0[b] = pa0[b] - pb0[b];
+                            hs1[b] = pa1[b] - pb1[b];
+                        }
                     }
 #pragma unroll
                     for (int b = 0; b < B; ++b) {
+                        // rows past the image bottom are staged from clamped loads and never referenced by an arm,
+                        // so they run through unconditionally (straight-line code) into ring rows nobody reads
                         const int y = ys + k * B + b;
-                        if (y <= ye) {         // rows past the image bottom are never referenced
-                            q0 += hs0[b];
-                            q1 += hs1[b];
-                            if (rl) {
-                                double2 qq;
-                                qq.x = q0;
-                                qq.y = q1;
-                                *reinterpret_cast<double2 *>(&ring[(y % RING) * RP + 2 * lane]) = qq;
-                            }
+                        q0 += hs0[b];
+                        q1 += hs1[b];
+                        if (rl) {
+                            double2 qq;
+                            qq.x = q0;
+                            qq.y = q1;
+                            *reinterpret_cast<double2 *>(&ring[(y % RING) * RP + 2 * lane]) = qq;
                         }
                     }
                     issue(slot, k + NPF);
@@ -410,17 +422,21 @@ __global__ __launch_bounds__(256) void cbca_pipe_kernel(const float *__restrict_
         }
     } else {
         // ---------------- emit role: batch t-2 ----------------
-        u32x2 so[NPF][B];
-        double rn0[NPF][B], rn1[NPF][B];
+        constexpr int EB = B;      // (splitting the rows over two emit waves, 320-thread workgroups, measured slower)
+        constexpr int e0 = 0;
+        constexpr int kDrop = 0x7ffffff0;          // byte offset past every plane: the range check drops the store
+        const int obm = oc1 ? ob : kDrop;
+        u32x2 so[NPF][EB];
+        double rn0[NPF][EB], rn1[NPF][EB];
         auto issue = [&](int slot, int k) {
 #pragma unroll
-            for (int b = 0; b < B; ++b)
+            for (int b = 0; b < EB; ++b)
                 so[slot][b] = __builtin_amdgcn_raw_buffer_load_b64(
-                    rs_sup, sb, min(max(ys + k * B + b - R, h0), h1 - 1) * rowv, 0);
+                    rs_sup, sb, min(max(ys + k * B + e0 + b - R, h0), h1 - 1) * rowv, 0);
         };
         auto recip = [&](int slot) {   // gathers 1/|U| for the rows of a batch whose support words have landed
 #pragma unroll
-            for (int b = 0; b < B; ++b) {
+            for (int b = 0; b < EB; ++b) {
                 rn0[slot][b] = kInv.v[(sstr ? so[slot][b].y : so[slot][b].x) >> 20];
                 rn1[slot][b] = kInv.v[so[slot][b].y >> 20];
             }
@@ -437,31 +453,45 @@ __global__ __launch_bounds__(256) void cbca_pipe_kernel(const float *__restrict_
                 const int slot = (u + NPF - 2) % NPF;
                 if (k >= 0 && k < nb) {
                     recip((slot + 1) % NPF);   // next batch's reciprocals, one iteration ahead of their use
+                    // Straight-line for the whole batch: all ring reads are issued before the first is consumed
+                    // (one LDS round trip per batch, not per row).  Rows outside the chunk compute on clamped
+                    // indices and their store is dropped by an out-of-range buffer offset.
+                    double qa0[EB], qb0[EB], qa1[EB], qb1[EB];
+                    const char *ringb = reinterpret_cast<const char *>(ring);
+                    const unsigned colb = 16u * (unsigned)lane;          // byte offset of column 2*lane in a ring row
 #pragma unroll
-                    for (int b = 0; b < B; ++b) {
-                        const int yo = ys + k * B + b - R;
-                        if (yo >= h0 && yo < h1) {
-                            const uint32_t a = sstr ? so[slot][b].y : so[slot][b].x, c = so[slot][b].y;
-                            const int col = 2 * lane;
-                            const int ym = yo % RING;   // wave-uniform; per-lane wrap by unsigned min
-                            auto below = [&](int up) {
-                                const int i = ym - up - 1;
-                                return (int)min((unsigned)i, (unsigned)(i + RING));
-                            };
-                            auto above = [&](int dn) {
-                                const int i = ym + dn;
-                                return (int)min((unsigned)i, (unsigned)(i - RING));
-                            };
-                            const double s0 = ring[above(arm_down(a)) * RP + col] - ring[below(arm_up(a)) * RP + col];
-                            const double s1 =
-                                ring[above(arm_down(c)) * RP + col + 1] - ring[below(arm_up(c)) * RP + col + 1];
-                            u32x2 o;
-                            o.x = __float_as_uint((float)(s0 * rn0[slot][b]));
-                            o.y = __float_as_uint((float)(s1 * rn1[slot][b]));
+                    for (int b = 0; b < EB; ++b) {
+                        const int yoc = min(max(ys + k * B + e0 + b - R, h0), h1 - 1);
+                        const uint32_t a = sstr ? so[slot][b].y : so[slot][b].x, c = so[slot][b].y;
+                        const int ym = yoc % RING;   // wave-uniform; per-lane wrap by unsigned min
+                        auto below = [&](int up) {
+                            const int i = ym - up - 1;
+                            return __umul24(min((unsigned)i, (unsigned)(i + RING)), RP * 8u);
+                        };
+                        auto above = [&](int dn) {
+                            const int i = ym + dn;
+                            return __umul24(min((unsigned)i, (unsigned)(i - RING)), RP * 8u);
+                        };
+                        qa0[b] = *reinterpret_cast<const double *>(ringb + above(arm_down(a)) + colb);
+                        qb0[b] = *reinterpret_cast<const double *>(ringb + below(arm_up(a)) + colb);
+                        qa1[b] = *reinterpret_cast<const double *>(ringb + above(arm_down(c)) + colb + 8);
+                        qb1[b] = *reinterpret_cast<const double *>(ringb + below(arm_up(c)) + colb + 8);
+                    }
+#pragma unroll
+                    for (int b = 0; b < EB; ++b) {
+                        const int yo = ys + k * B + e0 + b - R;
+                        const bool valid = yo >= h0 && yo < h1;      // wave-uniform
+                        const int yoc = min(max(yo, h0), h1 - 1);
+                        u32x2 o;
+                        o.x = __float_as_uint((float)((qa0[b] - qb0[b]) * rn0[slot][b]));
+                        o.y = __float_as_uint((float)((qa1[b] - qb1[b]) * rn1[slot][b]));
+                        if (!ODDW) {
+                            __builtin_amdgcn_raw_buffer_store_b64(o, rs_dst, valid ? obm : kDrop, yoc * rowv, 0);
+                        } else if (valid) {
                             if (oc1)
-                                __builtin_amdgcn_raw_buffer_store_b64(o, rs_dst, ob, yo * rowv, 0);
+                                __builtin_amdgcn_raw_buffer_store_b64(o, rs_dst, ob, yoc * rowv, 0);
                             else if (oc0)
-                                __builtin_amdgcn_raw_buffer_store_b32(o.x, rs_dst, ob, yo * rowv, 0);
+                                __builtin_amdgcn_raw_buffer_store_b32(o.x, rs_dst, ob, yoc * rowv, 0);
                         }
                     }
                     issue(slot, k + NPF);

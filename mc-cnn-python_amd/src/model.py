@@ -139,6 +139,17 @@ class NET(object):
         out = self._convs_nchw(x)[-1][0].contiguous()          # [64,H,W]
         return stereo_device.l2norm_chw_to_hwc(out)
 
+    def features_pair_hwc(self, left_hw, right_hw):
+        """Both views through the shared-weight stack as one batch of two (the Siamese towers are the same weights,
+        model.py:98 AUTO_REUSE / train.py:76-78): half the launches, twice the work per launch."""
+        import stereo_device
+        pad = (self.input_patch_size - 1) // 2
+        assert pad == self.num_conv_layers * (self.conv_kernel_size - 1) // 2
+        x = F.pad(torch.stack((left_hw, right_hw))[:, None], (pad, pad, pad, pad))   # [2,1,H+2p,W+2p]
+        out = self._convs_nchw(x)[-1]                                                  # [2,64,H,W]
+        return (stereo_device.l2norm_chw_to_hwc(out[0].contiguous()),
+                stereo_device.l2norm_chw_to_hwc(out[1].contiguous()))
+
 
 if __name__ == "__main__":
     net = NET(torch.zeros([128, 11, 11, 1]))

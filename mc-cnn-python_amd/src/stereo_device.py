@@ -296,8 +296,7 @@ class StereoMatcher(object):
         nd, nh = D * H * W, H * W * hwd[2]
 
         timer.start("features")
-        fl = self.net.features_hwc(L)
-        fr = self.net.features_hwc(R)
+        fl, fr = self.net.features_pair_hwc(L, R)
         timer.stop()
 
         timer.start("cost_volume")
