@@ -145,51 +145,96 @@ __global__ __launch_bounds__(256) void cost_volume_mfma_kernel(const float *__re
     // consecutive lanes write consecutive w (and consecutive w' = w - d).
     const size_t plane = (size_t)H * W;
     const int dbase = w0 - x0;  // d of the main diagonal
-    for (int diag = wave; diag < 127; diag += 4) {
+    // The vector-memory pipe costs the same per wave instruction whatever its width, so a lane stores 4 consecutive w
+    // (16 B, dword aligned) and one instruction covers 4 diagonals x 16 quads; the quads cut by the two ends of a
+    // diagonal fall back to scalar stores.
+    const int q = lane & 15, sub = lane >> 4;
+    for (int dg = wave; dg < 32; dg += 4) {
+        const int diag = dg * 4 + sub;
+        if (diag >= 127) continue;
         const int dd = diag - 63;      // w_local - x_local
         const int d = dbase + dd;
         if (d < 0 || d >= D) continue;
-        const int wl = lane;           // w_local
-        const int xl = wl - dd;        // x_local
-        if (xl < 0 || xl >= 64) continue;
+        const int wl = 4 * q;          // first w_local of this lane's quad
+        const int xl = wl - dd;        // matching x_local
+        if (xl + 3 < 0 || xl >= 64) continue;
         const int w = w0 + wl, x = x0 + xl;
-        if (w >= W || x < 0) continue;
-        const float s = -1.f * sS[wl * CVM_LD + xl];
-        lcv[(size_t)d * plane + rowbase + w] = s;
-        rcv[(size_t)d * plane + rowbase + x] = s;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int xj = min(max(xl + j, 0), 63);
+            v[j] = -1.f * sS[(wl + j) * CVM_LD + xj];
+        }
+        float *pl = lcv + (size_t)d * plane + rowbase + w;
+        float *pr = rcv + (size_t)d * plane + rowbase + x;
+        if (xl >= 0 && xl + 3 < 64 && w + 3 < W && x >= 0) {
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+            f4u o;
+            o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+            *reinterpret_cast<f4u *>(pl) = o;
+            *reinterpret_cast<f4u *>(pr) = o;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (xl + j >= 0 && xl + j < 64 && w + j < W && x + j >= 0) {
+                    pl[j] = v[j];
+                    pr[j] = v[j];
+                }
+        }
     }
 }
 
-// Border recurrences on the negated volumes.  One thread per (d, h); <= d sequential 3-tap steps each.
-__global__ __launch_bounds__(256) void cost_volume_fill_kernel(float *__restrict__ lcv, float *__restrict__ rcv,
-                                                               int D, int H, int W)
+// Border recurrences on the negated volumes.  One wavefront per (plane d, 64 image rows, side): lane = row, each lane
+// runs its own 3-tap recurrence (<= d sequential steps); 64 steps are staged in LDS and written back transposed, so the
+// stores are 256-byte runs along w instead of 64 scattered dwords per instruction.
+__global__ __launch_bounds__(64) void cost_volume_fill_kernel(float *__restrict__ lcv, float *__restrict__ rcv, int D,
+                                                              int H, int W)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= D * H) return;
-    const int d = idx / H, h = idx - d * H;
-    if (d == 0) return;
-    float *L = lcv + ((size_t)d * H + h) * W;
-    float *R = rcv + ((size_t)d * H + h) * W;
-    {   // pf:94-95: column w = d-1 .. 0 from columns w+1, w+2, w+3 (NumPy sums them in ascending order)
+    __shared__ float tile[64 * 65];
+    const int lane = threadIdx.x;
+    const int d = blockIdx.y + 1;              // plane 0 has no border
+    const int h0 = blockIdx.x * 64;
+    const int h = min(h0 + lane, H - 1);       // surplus lanes repeat the last row and store nothing
+    const int nrows = min(64, H - h0);
+    if (blockIdx.z == 0) {
+        // pf:94-95: column w = d-1 .. 0 from columns w+1, w+2, w+3 (NumPy sums them in ascending order)
+        float *L = lcv + ((size_t)d * H + h) * W;
         float x1 = L[d], x2 = L[d + 1], x3 = L[d + 2];
-        for (int w = d - 1; w >= 0; --w) {
-            float s = 0.f + x1;
-            s = s + x2;
-            s = s + x3;
-            const float v = s / 3.f;
-            L[w] = v;
-            x3 = x2; x2 = x1; x1 = v;
+        for (int wtop = d - 1; wtop >= 0; wtop -= 64) {
+            const int cnt = min(64, wtop + 1);
+            for (int j = 0; j < cnt; ++j) {
+                float s = 0.f + x1;
+                s = s + x2;
+                s = s + x3;
+                const float v = s / 3.f;
+                tile[lane * 65 + j] = v;
+                x3 = x2; x2 = x1; x1 = v;
+            }
+            __syncthreads();
+            if (lane < cnt)
+                for (int r = 0; r < nrows; ++r)
+                    lcv[((size_t)d * H + h0 + r) * W + (wtop - lane)] = tile[r * 65 + lane];
+            __syncthreads();
         }
-    }
-    {   // pf:105-106: column w = W-d .. W-1 from columns w-3, w-2, w-1
-        float x1 = R[W - d - 3], x2 = R[W - d - 2], x3 = R[W - d - 1];
-        for (int w = W - d; w < W; ++w) {
-            float s = 0.f + x1;
-            s = s + x2;
-            s = s + x3;
-            const float v = s / 3.f;
-            R[w] = v;
-            x1 = x2; x2 = x3; x3 = v;
+    } else {
+        // pf:105-106: column w = W-d .. W-1 from columns w-3, w-2, w-1
+        float *Rr = rcv + ((size_t)d * H + h) * W;
+        float x1 = Rr[W - d - 3], x2 = Rr[W - d - 2], x3 = Rr[W - d - 1];
+        for (int wbot = W - d; wbot < W; wbot += 64) {
+            const int cnt = min(64, W - wbot);
+            for (int j = 0; j < cnt; ++j) {
+                float s = 0.f + x1;
+                s = s + x2;
+                s = s + x3;
+                const float v = s / 3.f;
+                tile[lane * 65 + j] = v;
+                x1 = x2; x2 = x3; x3 = v;
+            }
+            __syncthreads();
+            if (lane < cnt)
+                for (int r = 0; r < nrows; ++r)
+                    rcv[((size_t)d * H + h0 + r) * W + (wbot + lane)] = tile[r * 65 + lane];
+            __syncthreads();
         }
     }
 }
@@ -219,6 +264,7 @@ extern "C" int mccnn_cost_volume(const float *fl, const float *fr, int H, int W,
     }
     int rc = check_launch("mccnn_cost_volume");
     if (rc) return rc;
-    hipLaunchKernelGGL(cost_volume_fill_kernel, dim3(cdiv((long)D * H, 256)), block, 0, s, lcv, rcv, D, H, W);
+    if (D > 1)
+        hipLaunchKernelGGL(cost_volume_fill_kernel, dim3(cdiv(H, 64), D - 1, 2), dim3(64), 0, s, lcv, rcv, D, H, W);
     return check_launch("mccnn_cost_volume(fill)");
 }

@@ -141,6 +141,50 @@ __global__ __launch_bounds__(256) void median_kernel(const float *__restrict__ d
     out[(size_t)h * W + w] = res;
 }
 
+// 5x5 window on images of at least 5x5 pixels (the only size match.py uses, match.py:172): the 25 taps live in
+// registers (out-of-window taps = +inf, which sorts behind every real value), an odd-even transposition network sorts
+// them with compile-time indices (no scratch memory), and the clipped window size n in {9,12,15,16,20,25} picks the rank.
+__global__ __launch_bounds__(256) void median5x5_kernel(const float *__restrict__ dl, int H, int W,
+                                                        float *__restrict__ out)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    const int h = blockIdx.y;
+    if (w >= W) return;
+    float v[25];
+    int n = 0;
+    bool has_nan = false;
+#pragma unroll
+    for (int dy = -2; dy <= 2; ++dy)
+#pragma unroll
+        for (int dx = -2; dx <= 2; ++dx) {
+            const int y = h + dy, x = w + dx;
+            const bool in = y >= 0 && y < H && x >= 0 && x < W;
+            const float t = in ? dl[(size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1)] : __builtin_huge_valf();
+            has_nan |= (t != t);
+            n += in ? 1 : 0;
+            v[(dy + 2) * 5 + dx + 2] = t;
+        }
+#pragma unroll
+    for (int pass = 0; pass < 25; ++pass)
+#pragma unroll
+        for (int i = pass & 1; i + 1 < 25; i += 2) {
+            const float lo = fminf(v[i], v[i + 1]), hi = fmaxf(v[i], v[i + 1]);
+            v[i] = lo;
+            v[i + 1] = hi;
+        }
+    float res;
+    switch (n) {
+        case 25: res = v[12]; break;
+        case 15: res = v[7]; break;
+        case 9: res = v[4]; break;
+        case 20: res = (v[9] + v[10]) / 2.f; break;    // np.mean of the two middle float32 values
+        case 16: res = (v[7] + v[8]) / 2.f; break;
+        default: res = (v[5] + v[6]) / 2.f; break;     // 12
+    }
+    if (has_nan) res = __builtin_nanf("");  // np.median propagates NaN
+    out[(size_t)h * W + w] = res;
+}
+
 // ---- a11 bilateral_filter (pf:440-466) --------------------------------------------------------------------------
 // NumPy float32 add.reduce over n contiguous values (pairwise_sum, n <= 128), then + identity.
 __device__ __forceinline__ float np_sum_small(const float *a, int n)
@@ -270,8 +314,11 @@ extern "C" int mccnn_median(const float *disp, int H, int W, int fh, int fw, flo
     MCCNN_REQUIRE(disp != out, MCCNN_E_INVALID, "mccnn_median: out must not alias the input map");
     MCCNN_REQUIRE(fh >= 1 && fw >= 1 && (fh & 1) && (fw & 1) && fh * fw <= MAXWIN, MCCNN_E_UNSUPPORTED,
                   "mccnn_median: window %dx%d must be odd x odd with at most %d taps", fh, fw, MAXWIN);
-    hipLaunchKernelGGL(median_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, (hipStream_t)stream, disp, H, W, fh, fw,
-                       out);
+    if (fh == 5 && fw == 5 && H >= 5 && W >= 5)
+        hipLaunchKernelGGL(median5x5_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, (hipStream_t)stream, disp, H, W, out);
+    else
+        hipLaunchKernelGGL(median_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, (hipStream_t)stream, disp, H, W, fh, fw,
+                           out);
     return check_launch("mccnn_median");
 }
 
