@@ -127,6 +127,7 @@ def main():
     algo = {
         "cbca_iter": 2 * vol_bytes,       # one iteration on one volume
         "sgm_pass": 2 * 2 * vol_bytes,    # one direction on BOTH volumes (one launch advances left + right)
+        "sgm_first_pass": 2 * 2 * vol_bytes,
     }
     rooflines = {}
     for k, b in algo.items():
@@ -138,7 +139,8 @@ def main():
                             "algorithmic_bytes_per_launch": int(b)}
     dominant = max(rooflines, key=lambda k: per_step[k]) if rooflines else None
     # SGM as a stage (what north_star's >= 50 % target is quoted on): 4 passes + the two layout changes
-    sgm_stage_ms = per_step.get("sgm_pass", 0.0) + per_step.get("dhw_to_hwd", 0.0) + per_step.get("hwd_to_dhw", 0.0)
+    sgm_stage_ms = (per_step.get("sgm_pass", 0.0) + per_step.get("sgm_first_pass", 0.0) +
+                    per_step.get("dhw_to_hwd", 0.0) + per_step.get("hwd_to_dhw", 0.0))
     result = {
         "metric": "Mdisparities/s (HxWxD / s) end-to-end match.py timed region",
         "value": round(value, 2), "unit": "Mdisparities/s", "n_gpus": world, "steps": args.steps,

@@ -107,6 +107,13 @@ int mccnn_sgm_pass(const float *image_left, const float *image_right, float *con
                    int n_jobs, int D, int H, int W, int rh, int rw, float p1, float p2, float q1, float q2, float thr,
                    void *scratch, size_t scratch_bytes, mccnn_stream_t stream);
 
+/* The first direction of SGM_average, r = (0,1) (pf:194-195, 216-217), fused with the layout change: reads the
+ * plane-major volumes vol_dhw[j] (left untouched) and writes the pixel-major vol_hwd[j], i.e. it replaces
+ * mccnn_dhw_to_hwd + mccnn_sgm_pass(rh=0, rw=1) and saves one full read + write of every volume.  2 <= D <= 256. */
+int mccnn_sgm_first_pass(const float *image_left, const float *image_right, const float *const *vol_dhw,
+                         float *const *vol_hwd, const int *side, int n_jobs, int D, int H, int W, float p1, float p2,
+                         float q1, float q2, float thr, void *scratch, size_t scratch_bytes, mccnn_stream_t stream);
+
 /* ---- a7  disparity_prediction, one volume (pf:239-272): first strict minimum over d, as float32 -------------- */
 int mccnn_wta(const float *vol_dhw, int D, int H, int W, float *disparity, mccnn_stream_t stream);
 

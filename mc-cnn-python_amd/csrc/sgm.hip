@@ -261,6 +261,168 @@ __global__ __launch_bounds__(64) void sgm_pass_kernel(const SgmParams P)
     }
 }
 
+// ---- first direction r = (0,1) fused with the DHW -> HWD layout change -------------------------------------------
+// SGM_average always starts with the left-to-right pass (pf:194-195), so that pass can read the plane-major volume
+// the aggregation left behind and write the pixel-major copy the other three passes work on: one full read + write
+// of the volume (dhw_to_hwd) disappears.  A wave still owns one image row.  Its disparity vectors are gathered 16
+// columns at a time: 16 x global_load_dwordx4 fetch a [256 d][16 w] tile (each plane row contributes one 64-byte
+// segment), registers -> LDS as [w][d], and each step reads its 4 disparities back with one ds_read_b128.  Tiles are
+// double buffered and the loads of tile k+2 are in flight while tile k is consumed.  D <= 256.
+struct SgmFirstJob {
+    const float *src;       // DHW volume (read only)
+    float *dst;             // HWD volume (written, including the untouched first column)
+    const uint8_t *aplane;
+    const uint8_t *bplane;
+    int dsign;
+};
+struct SgmFirstParams {
+    SgmFirstJob job[2];
+    int D, Dp, H, W, pitch, pad;
+    float p1[3], p2[3];
+};
+
+template <bool FULL>
+__global__ __launch_bounds__(64) void sgm_first_pass_kernel(const SgmFirstParams P)
+{
+    constexpr int TC = 16;          // columns per tile
+    constexpr int DP = 260;         // LDS pitch of one tile column (floats): 16-byte aligned, 2-way conflicts on the writes
+    __shared__ __attribute__((aligned(16))) float tile[2 * TC * DP];
+    const SgmFirstJob J = P.job[blockIdx.y];
+    const int lane = threadIdx.x;
+    const int h = blockIdx.x;
+    const int D = P.D, W = P.W;
+    const size_t plane = (size_t)P.H * W;
+    const int ntiles = (W + TC - 1) / TC;
+
+    // source: descriptor based at row h of plane 0; per-lane offset selects plane d and the 4-column group
+    const unsigned src_span = (unsigned)min((size_t)0xFFFFFFFFu, ((size_t)D * plane - (size_t)h * W) * 4);
+    const __amdgpu_buffer_rsrc_t rs_src =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(J.src + (size_t)h * W), 0, (int)src_span, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(
+        J.dst + (size_t)h * W * P.Dp, 0, (int)((size_t)W * P.Dp * 4), 0x00020000);
+    const size_t line_flag = (size_t)h * P.pitch + P.pad;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(J.aplane + line_flag),
+                                                                          0, W, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(J.bplane + line_flag - P.pad), 0, W + 2 * P.pad, 0x00020000);
+
+    constexpr int kDrop = 0x7ffffff0;
+    const int dl = lane * 4;
+    const bool act = FULL || dl < D;
+    const int voff = act ? 4 * dl : kDrop;                                   // HWD vector of this lane
+    const int boff = act ? P.pad + (J.dsign > 0 ? dl : -dl - 3) : kDrop;     // packed B flags
+    const int shl = J.dsign > 0 ? 0 : 24, sdir = J.dsign > 0 ? 8 : -8;
+    // tile gather: instruction i covers plane rows d = 16 i + (lane >> 2), columns 4 (lane & 3) .. +3
+    const int gr = lane >> 2, gc = (lane & 3) * 4;
+    unsigned goff[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int d = 16 * i + gr;
+        goff[i] = d < D ? (unsigned)((size_t)d * plane * 4) + 4u * gc : (unsigned)kDrop;
+    }
+    auto mask_tail = [&](float4 v) {
+        if (!FULL) {
+            if (dl + 0 >= D) v.x = kInf;
+            if (dl + 1 >= D) v.y = kInf;
+            if (dl + 2 >= D) v.z = kInf;
+            if (dl + 3 >= D) v.w = kInf;
+        }
+        return v;
+    };
+
+    sgm_u32x4 ld[16];           // the tile in flight
+    uint32_t fb[TC], fa[TC];    // flags of the tile being consumed next
+    auto issue_tile = [&](int k) {      // tile k -> registers (clamped past the last tile: harmless re-read)
+        const unsigned w0 = (unsigned)min(k, ntiles - 1) * TC * 4u;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ld[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, goff[i], w0, 0);
+    };
+    auto spill_tile = [&](int buf) {    // registers -> LDS [w][d]
+        float *t = tile + buf * TC * DP;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int d = 16 * i + gr;
+            t[(gc + 0) * DP + d] = __uint_as_float(ld[i].x);
+            t[(gc + 1) * DP + d] = __uint_as_float(ld[i].y);
+            t[(gc + 2) * DP + d] = __uint_as_float(ld[i].z);
+            t[(gc + 3) * DP + d] = __uint_as_float(ld[i].w);
+        }
+    };
+    auto issue_flags = [&](int k) {     // flags of the 16 steps of tile k
+#pragma unroll
+        for (int c = 0; c < TC; ++c) {
+            const unsigned w = (unsigned)min(k * TC + c, W - 1);
+            fa[c] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rs_a, 0, w, 0);
+            fb[c] = __builtin_amdgcn_raw_buffer_load_b32(rs_b, boff, w, 0);
+        }
+    };
+
+    issue_tile(0);
+    spill_tile(0);
+    issue_tile(1);
+    issue_flags(0);
+    __syncthreads();
+
+    float4 prev = make_float4(kInf, kInf, kInf, kInf);
+    float m = 0.f;
+    for (int k = 0; k < ntiles; ++k) {
+        const float *t = tile + (k & 1) * TC * DP;
+        uint32_t cfa[TC], cfb[TC];
+#pragma unroll
+        for (int c = 0; c < TC; ++c) { cfa[c] = fa[c]; cfb[c] = fb[c]; }
+        // next tile: registers -> the other LDS buffer (last read two tiles ago), then refill the registers
+        spill_tile((k + 1) & 1);
+        issue_tile(k + 2);
+        issue_flags(k + 1);
+#pragma unroll
+        for (int c = 0; c < TC; ++c) {
+            const int w = k * TC + c;
+            if (w >= W) continue;
+            const float4 cv = mask_tail(*reinterpret_cast<const float4 *>(&t[c * DP + dl]));
+            float4 o;
+            if (w == 0) {
+                o = cv;     // the first line of the scan is untouched (it only seeds the recurrence)
+            } else {
+                const int a = __builtin_amdgcn_readfirstlane((int)cfa[c]);
+                const float p1lo = a ? P.p1[1] : P.p1[0], p1hi = a ? P.p1[2] : P.p1[1];
+                const float p2lo = a ? P.p2[1] : P.p2[0], p2hi = a ? P.p2[2] : P.p2[1];
+                const float below = dpp_mov<0x138>(kInf, prev.w);
+                const float above = dpp_mov<0x130>(kInf, prev.x);
+                const uint32_t f = cfb[c];
+                const bool b0 = (f >> shl) & 1u, b1 = (f >> (shl + sdir)) & 1u, b2 = (f >> (shl + 2 * sdir)) & 1u,
+                           b3 = (f >> (shl + 3 * sdir)) & 1u;
+                {
+                    const float q1 = b0 ? p1hi : p1lo, q2 = b0 ? p2hi : p2lo;
+                    const float s = cv.x + vmin(vmin3(prev.x, below + q1, prev.y + q1), m + q2);
+                    o.x = s - m;
+                }
+                {
+                    const float q1 = b1 ? p1hi : p1lo, q2 = b1 ? p2hi : p2lo;
+                    const float s = cv.y + vmin(vmin3(prev.y, prev.x + q1, prev.z + q1), m + q2);
+                    o.y = s - m;
+                }
+                {
+                    const float q1 = b2 ? p1hi : p1lo, q2 = b2 ? p2hi : p2lo;
+                    const float s = cv.z + vmin(vmin3(prev.z, prev.y + q1, prev.w + q1), m + q2);
+                    o.z = s - m;
+                }
+                {
+                    const float q1 = b3 ? p1hi : p1lo, q2 = b3 ? p2hi : p2lo;
+                    const float s = cv.w + vmin(vmin3(prev.w, prev.z + q1, above + q1), m + q2);
+                    o.w = s - m;
+                }
+            }
+            sgm_u32x4 ou;
+            ou.x = __float_as_uint(o.x); ou.y = __float_as_uint(o.y);
+            ou.z = __float_as_uint(o.z); ou.w = __float_as_uint(o.w);
+            __builtin_amdgcn_raw_buffer_store_b128(ou, rs_dst, voff, (unsigned)w * (unsigned)P.Dp * 4u, 0);
+            prev = o;
+            m = wave_min(vmin(vmin(o.x, o.y), vmin(o.z, o.w)));
+        }
+        __syncthreads();   // single-wave workgroup: LDS writes of this iteration visible to the next one's reads
+    }
+}
+
 // ---- DHW <-> HWD: a [D x N] <-> [N x Dp] matrix transpose through a padded 64x64 LDS tile ------------------------
 __global__ __launch_bounds__(256) void dhw_to_hwd_kernel(const float *__restrict__ dhw, float *__restrict__ hwd, int D,
                                                          long N, int Dp)
@@ -305,25 +467,31 @@ __global__ __launch_bounds__(256) void hwd_to_dhw_kernel(const float *__restrict
 // out[c][r] = in[r][c] for r < R, c < Cw, with 16-byte accesses on both global sides (the vector-memory pipe costs the
 // same per wave instruction whatever its width).  Requires C, ip, op multiples of 4 and 16-byte aligned bases; Rw is
 // the number of out columns to write rounded up to 4 (pad columns receive zeros).
+template <int TRI>   // input rows per tile = length of the contiguous output runs (in floats)
 __global__ __launch_bounds__(256) void transpose_f4_kernel(const float *__restrict__ in, float *__restrict__ out, long R,
                                                            long C, long ip, long op, long Cw, long Rw)
 {
-    __shared__ float tile[64 * 65];
-    const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
-    const int q = threadIdx.x & 15, p = threadIdx.x >> 4;
+    __shared__ float tile[TRI * 65];
+    const long r0 = (long)blockIdx.y * TRI, c0 = (long)blockIdx.x * 64;
+    {
+        const int q = threadIdx.x & 15, p = threadIdx.x >> 4;   // 16 float4 per 64-wide input row, 16 rows per pass
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-        const int r = p + 16 * pass;
-        const long gr = r0 + r, gc = c0 + 4 * q;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gr < R && gc < C) v = *reinterpret_cast<const float4 *>(in + gr * ip + gc);
-        float *t = &tile[r * 65 + 4 * q];
-        t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+        for (int pass = 0; pass < TRI / 16; ++pass) {
+            const int r = p + 16 * pass;
+            const long gr = r0 + r, gc = c0 + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gr < R && gc < C) v = *reinterpret_cast<const float4 *>(in + gr * ip + gc);
+            float *t = &tile[r * 65 + 4 * q];
+            t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+        }
     }
     __syncthreads();
+    constexpr int QN = TRI / 4;          // float4 per output row of the tile
+    constexpr int PN = 256 / QN;         // output rows per pass
+    const int q = threadIdx.x % QN, p = threadIdx.x / QN;
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-        const int c = p + 16 * pass;
+    for (int pass = 0; pass < 64 / PN; ++pass) {
+        const int c = p + PN * pass;
         const long gc = c0 + c, gr = r0 + 4 * q;
         if (gc < Cw && gr < Rw) {
             float4 v;
@@ -350,8 +518,8 @@ extern "C" int mccnn_dhw_to_hwd(const float *dhw, float *hwd, int D, int H, int 
     const long N = (long)H * W;
     const int Dp = mccnn_hwd_pitch(D);
     if ((N & 3) == 0 && ((uintptr_t)dhw & 15) == 0 && ((uintptr_t)hwd & 15) == 0)   // in: [D][N], out: [N][Dp]
-        hipLaunchKernelGGL(transpose_f4_kernel, dim3(cdiv(N, 64), cdiv(D, 64)), dim3(256), 0, (hipStream_t)stream, dhw,
-                           hwd, (long)D, N, N, (long)Dp, N, (long)Dp);
+        hipLaunchKernelGGL(transpose_f4_kernel<64>, dim3(cdiv(N, 64), cdiv(D, 64)), dim3(256), 0, (hipStream_t)stream,
+                           dhw, hwd, (long)D, N, N, (long)Dp, N, (long)Dp);
     else
         hipLaunchKernelGGL(dhw_to_hwd_kernel, dim3(cdiv(N, 64), cdiv(Dp, 64)), dim3(256), 0, (hipStream_t)stream, dhw,
                            hwd, D, N, Dp);
@@ -366,8 +534,8 @@ extern "C" int mccnn_hwd_to_dhw(const float *hwd, float *dhw, int D, int H, int 
     const long N = (long)H * W;
     const int Dp = mccnn_hwd_pitch(D);
     if ((N & 3) == 0 && ((uintptr_t)dhw & 15) == 0 && ((uintptr_t)hwd & 15) == 0)   // in: [N][Dp], out: [D][N]
-        hipLaunchKernelGGL(transpose_f4_kernel, dim3(cdiv(Dp, 64), cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, hwd,
-                           dhw, N, (long)Dp, (long)Dp, N, (long)D, N);
+        hipLaunchKernelGGL(transpose_f4_kernel<128>, dim3(cdiv(Dp, 64), cdiv(N, 128)), dim3(256), 0,
+                           (hipStream_t)stream, hwd, dhw, N, (long)Dp, (long)Dp, N, (long)D, N);   // 512-byte runs
     else
         hipLaunchKernelGGL(hwd_to_dhw_kernel, dim3(cdiv(N, 64), cdiv(D, 64)), dim3(256), 0, (hipStream_t)stream, hwd,
                            dhw, D, N, Dp);
@@ -437,4 +605,54 @@ extern "C" int mccnn_sgm_pass(const float *image_left, const float *image_right,
     else
         hipLaunchKernelGGL((sgm_pass_kernel<2, 4, false>), grid, block, 0, s, P);
     return check_launch("mccnn_sgm_pass");
+}
+
+extern "C" int mccnn_sgm_first_pass(const float *image_left, const float *image_right, const float *const *vol_dhw,
+                                    float *const *vol_hwd, const int *side, int n_jobs, int D, int H, int W, float p1,
+                                    float p2, float q1, float q2, float thr, void *scratch, size_t scratch_bytes,
+                                    mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(image_left && image_right && vol_dhw && vol_hwd && side && scratch, MCCNN_E_INVALID,
+                  "mccnn_sgm_first_pass: null pointer");
+    MCCNN_REQUIRE(n_jobs == 1 || n_jobs == 2, MCCNN_E_INVALID, "mccnn_sgm_first_pass: n_jobs=%d must be 1 or 2", n_jobs);
+    MCCNN_REQUIRE(H > 0 && W > 1, MCCNN_E_INVALID, "mccnn_sgm_first_pass: bad size");
+    MCCNN_REQUIRE(D >= 2 && D <= 256, MCCNN_E_UNSUPPORTED,
+                  "mccnn_sgm_first_pass: D=%d outside [2,256]; use mccnn_dhw_to_hwd + mccnn_sgm_pass", D);
+    MCCNN_REQUIRE((size_t)D * H * W * 4 < ((size_t)1 << 32), MCCNN_E_UNSUPPORTED,
+                  "mccnn_sgm_first_pass: volume exceeds the 4 GiB reach of a buffer descriptor");
+    MCCNN_REQUIRE(scratch_bytes >= mccnn_sgm_scratch_bytes(H, W, D), MCCNN_E_SCRATCH,
+                  "mccnn_sgm_first_pass: scratch %zu < %zu bytes", scratch_bytes, mccnn_sgm_scratch_bytes(H, W, D));
+    hipStream_t s = (hipStream_t)stream;
+    const int pad = flag_pad(D);
+    const int pitch = W + 2 * pad;
+    uint8_t *plane_l = reinterpret_cast<uint8_t *>(scratch);
+    uint8_t *plane_r = plane_l + (((size_t)H * pitch + 127) & ~(size_t)127);
+    const dim3 fgrid(cdiv(pitch, 256), H), fblock(256);
+    hipLaunchKernelGGL(sgm_flags_kernel, fgrid, fblock, 0, s, image_left, H, W, 0, 1, thr, pitch, pad, plane_l);
+    hipLaunchKernelGGL(sgm_flags_kernel, fgrid, fblock, 0, s, image_right, H, W, 0, 1, thr, pitch, pad, plane_r);
+    int rc = check_launch("mccnn_sgm_first_pass(flags)");
+    if (rc) return rc;
+    SgmFirstParams P;
+    for (int j = 0; j < 2; ++j) {
+        const int jj = j < n_jobs ? j : 0;
+        MCCNN_REQUIRE(vol_dhw[jj] && vol_hwd[jj], MCCNN_E_INVALID, "mccnn_sgm_first_pass: null volume");
+        MCCNN_REQUIRE(side[jj] == MCCNN_SIDE_LEFT || side[jj] == MCCNN_SIDE_RIGHT, MCCNN_E_INVALID,
+                      "mccnn_sgm_first_pass: side must be MCCNN_SIDE_LEFT or MCCNN_SIDE_RIGHT");
+        const bool left = side[jj] == MCCNN_SIDE_LEFT;
+        P.job[j].src = vol_dhw[jj];
+        P.job[j].dst = vol_hwd[jj];
+        P.job[j].aplane = left ? plane_l : plane_r;
+        P.job[j].bplane = left ? plane_r : plane_l;
+        P.job[j].dsign = left ? -1 : +1;
+    }
+    P.D = D; P.Dp = mccnn_hwd_pitch(D); P.H = H; P.W = W; P.pitch = pitch; P.pad = pad;
+    P.p1[0] = p1; P.p1[1] = p1 / q1; P.p1[2] = p1 / q2;
+    P.p2[0] = p2; P.p2[1] = p2 / q1; P.p2[2] = p2 / q2;
+    const dim3 grid(H, n_jobs), block(64);
+    if (D == 256)
+        hipLaunchKernelGGL((sgm_first_pass_kernel<true>), grid, block, 0, s, P);
+    else
+        hipLaunchKernelGGL((sgm_first_pass_kernel<false>), grid, block, 0, s, P);
+    return check_launch("mccnn_sgm_first_pass");
 }

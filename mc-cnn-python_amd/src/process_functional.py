@@ -141,10 +141,12 @@ def SGM_average(left_cost_volume, right_cost_volume, left_image, right_image,
     vl, was_np = _dev(left_cost_volume)
     vr, _ = _dev(right_cost_volume)
     D, H, W = vl.shape
-    hl, hr = sd.dhw_to_hwd(vl), sd.dhw_to_hwd(vr)
+    hwd_shape = (H, W, sd.hwd_pitch(D))
+    hl = torch.empty(hwd_shape, dtype=torch.float32, device=vl.device)
+    hr = torch.empty(hwd_shape, dtype=torch.float32, device=vl.device)
     scratch = sd.sgm_scratch(H, W, D, vl.device)
-    sd.sgm_average_hwd(L, R, [hl, hr], [hip.MCCNN_SIDE_LEFT, hip.MCCNN_SIDE_RIGHT], D, sgm_P1, sgm_P2, sgm_Q1, sgm_Q2,
-                       sgm_D, sgm_V, scratch)
+    sd.sgm_average_from_dhw(L, R, [vl, vr], [hl, hr], [hip.MCCNN_SIDE_LEFT, hip.MCCNN_SIDE_RIGHT], D, sgm_P1, sgm_P2,
+                            sgm_Q1, sgm_Q2, sgm_D, sgm_V, scratch)
     ol, orr = sd.hwd_to_dhw(hl, D), sd.hwd_to_dhw(hr, D)
     if was_np:
         ol_np, or_np = ol.cpu().numpy(), orr.cpu().numpy()

@@ -179,6 +179,42 @@ def sgm_average_hwd(image_left, image_right, vols_hwd, sides, D, sgm_P1, sgm_P2,
         timer.stop()
 
 
+SGM_FIRST_PASS_MAX_D = 256  # mccnn_sgm_first_pass gathers one [256 d][16 w] tile per wave
+
+
+def sgm_average_from_dhw(image_left, image_right, vols_dhw, vols_hwd, sides, D, sgm_P1, sgm_P2, sgm_Q1, sgm_Q2, sgm_D,
+                         sgm_V, scratch, timer=_NO_TIMER):
+    """SGM_average starting from plane-major volumes: the first direction (0,1) reads `vols_dhw` and writes the
+    pixel-major `vols_hwd` (mccnn_sgm_first_pass: layout change fused into the pass), the other three run in place on
+    `vols_hwd`.  For D > 256 the layout change is a separate launch."""
+    H, W = image_left.shape
+    p1h = _f32(sgm_P1)
+    p1v = _f32(sgm_P1 / sgm_V)
+    p2, q1, q2, thr = _f32(sgm_P2), _f32(sgm_Q1), _f32(sgm_Q2), _f32(sgm_D)
+    n = len(vols_dhw)
+    rest = SGM_DIRECTIONS
+    if D <= SGM_FIRST_PASS_MAX_D:
+        src = (ctypes.c_void_p * 2)(*([v.data_ptr() for v in vols_dhw] + [None] * (2 - n)))
+        dst = (ctypes.c_void_p * 2)(*([v.data_ptr() for v in vols_hwd] + [None] * (2 - n)))
+        side_arr = (ctypes.c_int * 2)(*(list(sides) + [0] * (2 - n)))
+        timer.start("sgm_first_pass")
+        hip.check(hip.load().mccnn_sgm_first_pass(hip.ptr(image_left), hip.ptr(image_right), src, dst, side_arr, n,
+                                                  int(D), H, W, p1h, p2, q1, q2, thr, hip.ptr(scratch),
+                                                  scratch.numel(), hip.stream()), "mccnn_sgm_first_pass")
+        timer.stop()
+        rest = SGM_DIRECTIONS[1:]
+    else:
+        timer.start("dhw_to_hwd")
+        for a, b in zip(vols_dhw, vols_hwd):
+            dhw_to_hwd(a, b)
+        timer.stop()
+    for r in rest:
+        timer.start("sgm_pass")
+        sgm_pass_hwd(image_left, image_right, vols_hwd, sides, D, r, p1h if r[0] == 0 else p1v, p2, q1, q2, thr,
+                     scratch)
+        timer.stop()
+
+
 # ---- a7 .. a11 -----------------------------------------------------------------------------------------------------
 def wta(vol):
     D, H, W = vol.shape
@@ -320,12 +356,9 @@ class StereoMatcher(object):
             keep["cbca1"] = (lcv.clone(), rcv.clone())
 
         # SGM on pixel-major copies; t1d/t2d are the spare buffers (possibly swapped with ws[lcv/rcv] by the ping-pong)
-        timer.start("dhw_to_hwd")
-        lh = dhw_to_hwd(lcv, self._as_hwd(t1d, ws, hwd, nh))
-        rh = dhw_to_hwd(rcv, self._as_hwd(t2d, ws, hwd, nh))
-        timer.stop()
-        sgm_average_hwd(L, R, [lh, rh], [hip.MCCNN_SIDE_LEFT, hip.MCCNN_SIDE_RIGHT], D, hp["sgm_P1"], hp["sgm_P2"],
-                        hp["sgm_Q1"], hp["sgm_Q2"], hp["sgm_D"], hp["sgm_V"], ws["scratch"], timer)
+        lh, rh = self._as_hwd(t1d, ws, hwd, nh), self._as_hwd(t2d, ws, hwd, nh)
+        sgm_average_from_dhw(L, R, [lcv, rcv], [lh, rh], [hip.MCCNN_SIDE_LEFT, hip.MCCNN_SIDE_RIGHT], D, hp["sgm_P1"],
+                             hp["sgm_P2"], hp["sgm_Q1"], hp["sgm_Q2"], hp["sgm_D"], hp["sgm_V"], ws["scratch"], timer)
         timer.start("hwd_to_dhw")
         hwd_to_dhw(lh, D, lcv)
         hwd_to_dhw(rh, D, rcv)
