@@ -20,7 +20,8 @@
  *   features  [H][W][C]     float32, C = 64 (NET.features, NHWC)
  *   volume    "DHW" [D][H][W]   - the reference's layout; cost volume, CBCA, WTA, sub-pixel use it
  *             "HWD" [H][W][Dp]  - pixel-major, Dp = mccnn_hwd_pitch(D); the SGM scanline kernels use it
- *   support   [H][W]        uint32 words: four 5-bit cross-arm lengths + 12-bit region size (mccnn_support_t)
+ *   support   mccnn_support_bytes(H,W) bytes: plane 0 [H][W] uint32 words (four 5-bit cross-arm lengths + 12-bit
+ *             region size, mccnn_support_t), plane 1 [H][W] uint64 "emit words" (1/size as float64 + vertical arms)
  *   maps      [H][W]        float32 disparity maps, int32 status / region counts
  */
 #ifndef MCCNN_H
@@ -64,8 +65,14 @@ int mccnn_cost_volume(const float *fl, const float *fr, int H, int W, int C, int
  * kernel fetches everything about two neighbouring pixels with one 8-byte load:
  *     bits 0-4 up | 5-9 down | 10-14 left | 15-19 right | 20-31 count        (arms <= 31, count <= 63*63)
  * hence L <= 32.  The reference's explicit coordinate list [H][W][(2L)^2][2] (padded with -1) is produced by
- * mccnn_cross_region_list for API compatibility only. */
-typedef uint32_t mccnn_support_t; /* plane layout [H][W] */
+ * mccnn_cross_region_list for API compatibility only.
+ * The support buffer holds a second, derived plane behind the first (16-byte aligned, at byte offset
+ * roundup(H*W*4, 16)): [H][W] uint64 "emit words" = the bits of the float64 reciprocal 1/count rounded to 42
+ * mantissa bits, with the freed low 10 bits carrying up (0-4) and down (5-9).  mccnn_cbca_iter's streaming kernel
+ * reads it with one 16-byte load per two outputs.  Allocate mccnn_support_bytes(H, W) bytes; mccnn_cross_arms fills
+ * both planes, and consumers that only want the arms / counts read the first H*W words. */
+typedef uint32_t mccnn_support_t; /* plane 0 layout [H][W] */
+size_t mccnn_support_bytes(int H, int W); /* whole buffer: both planes (0 for non-positive sizes) */
 #define MCCNN_SUPPORT_UP(s) ((s) & 31u)
 #define MCCNN_SUPPORT_DOWN(s) (((s) >> 5) & 31u)
 #define MCCNN_SUPPORT_LEFT(s) (((s) >> 10) & 31u)

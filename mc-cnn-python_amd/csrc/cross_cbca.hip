@@ -71,6 +71,16 @@ __global__ __launch_bounds__(256) void cross_arms_kernel(const float *__restrict
 // pf:640-653: region size = sum over the vertical arm of the horizontal arm sizes.  The size goes into the upper 12
 // bits of the same word whose lower 20 bits (the arms, written by the previous kernel and never changed here) the
 // neighbours are reading: relaxed atomics make that formally race-free, and any mix of old/new words is correct.
+//
+// The same kernel fills the second plane of the support buffer, the 8-byte "emit words" the streaming aggregation
+// kernel reads once per output: the float64 reciprocal 1/n rounded to 42 mantissa bits, whose 10 freed low bits
+// carry the vertical arms (0-4 up, 5-9 down).  One 16-byte load per lane then brings everything the emit stage needs
+// for two pixels, instead of a support word plus two table gathers (which cost ~55 cache-line lookups each).
+__host__ __device__ __forceinline__ size_t emit_plane_offset(int H, int W)
+{
+    return ((size_t)H * W * 4 + 15) & ~(size_t)15;
+}
+
 __global__ __launch_bounds__(256) void cross_count_kernel(Support *__restrict__ sup, int H, int W)
 {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -84,6 +94,11 @@ __global__ __launch_bounds__(256) void cross_count_kernel(Support *__restrict__ 
         n += arm_left(aq) + arm_right(aq) + 1;
     }
     __hip_atomic_fetch_or(&sup[(size_t)h * W + w], n << 20, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long bits = (unsigned long long)__double_as_longlong(1.0 / (double)n);
+    bits = (bits + 0x200ull) & ~0x3ffull;          // round to nearest at 42 mantissa bits
+    unsigned long long *emitw =
+        reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(sup) + emit_plane_offset(H, W));
+    emitw[(size_t)h * W + w] = bits | (a & 0x3ffu);
 }
 
 // pf:637-655: explicit list, order (self, up.., down..) x (self, left.., right..), padded with (-1,-1)
@@ -238,21 +253,9 @@ __device__ __forceinline__ double dpp_f64(double x)
     return __hiloint2double(hi, lo);
 }
 
-// 1/n for the region sizes n <= 63*63, rounded to float64 at compile time: the emit stage gathers it (the 32 KB table
-// stays cache resident) instead of spending ~40 VALU cycles per output on a float64 reciprocal, multiplies the float64
-// region sum by it and rounds once to float32 - the correctly rounded quotient up to ~1e-8 of near-ties.
-struct InvTable {
-    double v[4096];
-    constexpr InvTable() : v()
-    {
-        v[0] = 0.0;
-        for (int i = 1; i < 4096; ++i) v[i] = 1.0 / (double)i;
-    }
-};
-__device__ const InvTable kInv = InvTable();
-
 constexpr int CS_IN = 128;  // staged columns per strip (2 per lane)
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <int R, int RING, bool ODDW>
 __global__ __launch_bounds__(256) void cbca_pipe_kernel(const float *__restrict__ in, float *__restrict__ out,
@@ -271,7 +274,23 @@ __global__ __launch_bounds__(256) void cbca_pipe_kernel(const float *__restrict_
     __shared__ double prow[2 * B * PRP];       // double-buffered by batch parity
     __shared__ double ring[RING * RP];
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform role id
+    // Role of this wave.  The dispatcher puts the four waves of a workgroup on the four SIMDs of a CU with a start
+    // SIMD that varies per workgroup, so with roles tied to the wave index a SIMD can end up hosting several emit
+    // waves (the longest stage) of the four resident workgroups.  Role = (SIMD id + wave slot) mod 4 gives every
+    // SIMD one wave of each role when resident workgroups occupy equal slots; if the four waves do not come out
+    // with four distinct roles (placement is not architecturally guaranteed), fall back to the wave index.
+    __shared__ int claim[4];
+    int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    {
+        uint32_t hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));   // [3:0] wave slot, [5:4] SIMD
+        const int pref = (int)(((hw >> 4) + hw) & 3u);
+        if (lane == 0) claim[wave] = pref;
+        __syncthreads();
+        const int seen = (1 << claim[0]) | (1 << claim[1]) | (1 << claim[2]) | (1 << claim[3]);
+        if (seen == 15) wave = pref;
+        wave = __builtin_amdgcn_readfirstlane(wave);
+    }
     // XCD-aware order: consecutive work items (neighbouring strips of one plane share halo columns) stay on one
     // XCD's L2; the dispatcher places block b on XCD b % 8 (speed only, any placement is correct)
     int id;
@@ -302,6 +321,9 @@ __global__ __launch_bounds__(256) void cbca_pipe_kernel(const float *__restrict_
         __builtin_amdgcn_make_buffer_rsrc(out + (size_t)d * plane, 0, (int)(plane * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_sup =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<Support *>(sup), 0, (int)(plane * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_emit = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(sup)) + emit_plane_offset(H, W), 0, (int)(plane * 8),
+        0x00020000);
     const int vb = 4 * x0c, sb = 4 * c0c, ob = 4 * c0;
     const int rowv = 4 * W;
 
@@ -426,24 +448,15 @@ __global__ __launch_bounds__(256) void cbca_pipe_kernel(const float *__restrict_
         constexpr int e0 = 0;
         constexpr int kDrop = 0x7ffffff0;          // byte offset past every plane: the range check drops the store
         const int obm = oc1 ? ob : kDrop;
-        u32x2 so[NPF][EB];
-        double rn0[NPF][EB], rn1[NPF][EB];
+        u32x4 so[NPF][EB];                         // emit words of the two output pixels: {lo0, hi0, lo1, hi1}
         auto issue = [&](int slot, int k) {
 #pragma unroll
             for (int b = 0; b < EB; ++b)
-                so[slot][b] = __builtin_amdgcn_raw_buffer_load_b64(
-                    rs_sup, sb, min(max(ys + k * B + e0 + b - R, h0), h1 - 1) * rowv, 0);
-        };
-        auto recip = [&](int slot) {   // gathers 1/|U| for the rows of a batch whose support words have landed
-#pragma unroll
-            for (int b = 0; b < EB; ++b) {
-                rn0[slot][b] = kInv.v[(sstr ? so[slot][b].y : so[slot][b].x) >> 20];
-                rn1[slot][b] = kInv.v[so[slot][b].y >> 20];
-            }
+                so[slot][b] = __builtin_amdgcn_raw_buffer_load_b128(
+                    rs_emit, 2 * sb, min(max(ys + k * B + e0 + b - R, h0), h1 - 1) * (2 * rowv), 0);
         };
 #pragma unroll
         for (int k = 0; k < NPF; ++k) issue(k, k);
-        recip(0);
         for (int tb = 0; tb < nb + 2; tb += NPF) {
 #pragma unroll
             for (int u = 0; u < NPF; ++u) {
@@ -452,7 +465,6 @@ __global__ __launch_bounds__(256) void cbca_pipe_kernel(const float *__restrict_
                 const int k = t - 2;
                 const int slot = (u + NPF - 2) % NPF;
                 if (k >= 0 && k < nb) {
-                    recip((slot + 1) % NPF);   // next batch's reciprocals, one iteration ahead of their use
                     // Straight-line for the whole batch: all ring reads are issued before the first is consumed
                     // (one LDS round trip per batch, not per row).  Rows outside the chunk compute on clamped
                     // indices and their store is dropped by an out-of-range buffer offset.
@@ -462,7 +474,7 @@ __global__ __launch_bounds__(256) void cbca_pipe_kernel(const float *__restrict_
 #pragma unroll
                     for (int b = 0; b < EB; ++b) {
                         const int yoc = min(max(ys + k * B + e0 + b - R, h0), h1 - 1);
-                        const uint32_t a = sstr ? so[slot][b].y : so[slot][b].x, c = so[slot][b].y;
+                        const uint32_t a = sstr ? so[slot][b].z : so[slot][b].x, c = so[slot][b].z;
                         const int ym = yoc % RING;   // wave-uniform; per-lane wrap by unsigned min
                         auto below = [&](int up) {
                             const int i = ym - up - 1;
@@ -483,8 +495,11 @@ __global__ __launch_bounds__(256) void cbca_pipe_kernel(const float *__restrict_
                         const bool valid = yo >= h0 && yo < h1;      // wave-uniform
                         const int yoc = min(max(yo, h0), h1 - 1);
                         u32x2 o;
-                        o.x = __float_as_uint((float)((qa0[b] - qb0[b]) * rn0[slot][b]));
-                        o.y = __float_as_uint((float)((qa1[b] - qb1[b]) * rn1[slot][b]));
+                        const u32x4 e = so[slot][b];
+                        const double rn0 = __hiloint2double((int)(sstr ? e.w : e.y), (int)((sstr ? e.z : e.x) & ~0x3ffu));
+                        const double rn1 = __hiloint2double((int)e.w, (int)(e.z & ~0x3ffu));
+                        o.x = __float_as_uint((float)((qa0[b] - qb0[b]) * rn0));
+                        o.y = __float_as_uint((float)((qa1[b] - qb1[b]) * rn1));
                         if (!ODDW) {
                             __builtin_amdgcn_raw_buffer_store_b64(o, rs_dst, valid ? obm : kDrop, yoc * rowv, 0);
                         } else if (valid) {
@@ -528,6 +543,12 @@ static int launch_cbca_pipe(const float *in, float *out, const Support *sup, int
 }
 
 }  // namespace mccnn
+
+extern "C" size_t mccnn_support_bytes(int H, int W)
+{
+    if (H <= 0 || W <= 0) return 0;
+    return mccnn::emit_plane_offset(H, W) + (size_t)H * W * 8;
+}
 
 extern "C" int mccnn_cross_arms(const float *image, int H, int W, float tau, int L, mccnn_support_t *support,
                                 mccnn_stream_t stream)

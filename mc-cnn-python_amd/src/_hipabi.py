@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libmccnn_hip.so")
+# MCCNN_HIP_LIB selects another build of the same library (kernel A/B measurements); there is still no CPU path.
+LIB_PATH = os.environ.get("MCCNN_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libmccnn_hip.so")
 
 MCCNN_CV_EXACT = 0
 MCCNN_CV_MFMA = 1
@@ -28,6 +29,7 @@ SIGNATURES = {
     "mccnn_version": (_i, []),
     "mccnn_last_error_string": (ctypes.c_char_p, []),
     "mccnn_cost_volume": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "mccnn_support_bytes": (_sz, [_i, _i]),
     "mccnn_cross_arms": (_i, [_vp, _i, _i, _f, _i, _vp, _vp]),
     "mccnn_cross_region_list": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mccnn_cbca_iter": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

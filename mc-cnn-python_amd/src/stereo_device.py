@@ -78,9 +78,13 @@ def cost_volume(fl, fr, ndisp, mode=hip.MCCNN_CV_EXACT, out=None):
 # ---- a3 ----------------------------------------------------------------------------------------------------------
 def cross_arms(image, intensity_threshold, distance_threshold):
     """image [H,W] -> support plane, int32 [H,W]: one packed word per pixel (mccnn_support_t: bits 0-4 up, 5-9 down,
-    10-14 left, 15-19 right, 20-31 region size).  support_arms()/support_count() decode it."""
+    10-14 left, 15-19 right, 20-31 region size).  support_arms()/support_count() decode it.  The returned tensor is
+    a view of the first plane of a mccnn_support_bytes(H, W) buffer; the derived second plane (the 8-byte words the
+    streaming CBCA kernel reads) lives behind it in the same storage and travels with the view."""
     H, W = image.shape
-    support = torch.empty((H, W), dtype=torch.int32, device=image.device)
+    nbytes = int(hip.load().mccnn_support_bytes(H, W))
+    buf = torch.empty(((nbytes + 3) // 4,), dtype=torch.int32, device=image.device)
+    support = buf[:H * W].view(H, W)
     hip.check(hip.load().mccnn_cross_arms(hip.ptr(image), H, W, _f32(intensity_threshold), int(distance_threshold),
                                           hip.ptr(support), hip.stream()), "mccnn_cross_arms")
     return support
@@ -113,6 +117,9 @@ def cbca(vol, tmp, support, iterations, distance_threshold, order=hip.MCCNN_CBCA
     callers that need the input keep their own copy."""
     D, H, W = vol.shape
     lib = hip.load()
+    have = support.untyped_storage().nbytes() - support.storage_offset() * support.element_size()
+    if tuple(support.shape) != (H, W) or not support.is_contiguous() or have < lib.mccnn_support_bytes(H, W):
+        raise ValueError("cbca: `support` must be the tensor cross_arms() returned (a copy drops its second plane)")
     src, dst = vol, tmp
     timer = timer or _NO_TIMER
     for _ in range(int(iterations)):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: bash tools/pmc_kernel.sh <bench_kernels --only name> <kernel-name substring>   (run on the GPU box)
 # Collects a few rocprofv3 PMC sets (separate passes: --pmc must not be combined with tracing) and prints per-dispatch means.
-ONLY=${1:-cbca_iter}; KSUB=${2:-cbca_stream}
+ONLY=${1:-cbca_iter}; KSUB=${2:-cbca_pipe}
 export TMPDIR=/tmp; R=$PWD; OUT=$R/gpurun_out/pmc_$ONLY; rm -rf $OUT; cd /tmp
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS" \
