@@ -144,9 +144,15 @@ int mccnn_median(const float *disp, int H, int W, int fh, int fw, float *out, mc
 int mccnn_bilateral(const float *image, const float *disp, int H, int W, int fh, int fw, const float *table,
                     float thr, float *out, mccnn_stream_t stream);
 
-/* ---- a1 epilogue: tf.nn.l2_normalize over channels (model.py:64), x * rsqrt(max(sum x^2, 1e-12)) -----------
- * in: NCHW [C][H][W] (what the PyTorch-ROCm conv stack produces) -> out: NHWC [H][W][C] unit vectors. */
-int mccnn_l2norm_chw_to_hwc(const float *chw, float *hwc, int C, int H, int W, mccnn_stream_t stream);
+/* ---- a1 epilogues of the conv stack (model.py:51-64, 111-125) ------------------------------------------------
+ * mccnn_bias_act: x[n][c][i] = act(x[n][c][i] + bias[c]) in place on an NCHW tensor (plane = H*W elements) -
+ *   tf.nn.bias_add + tf.nn.relu of model.py:118-123 in ONE pass over the activations (relu != 0), or the bias
+ *   alone (relu == 0).  The convolution itself runs in PyTorch-ROCm/MIOpen without bias.
+ * mccnn_l2norm_chw_to_hwc: tf.nn.l2_normalize over channels (model.py:64), x * rsqrt(max(sum x^2, 1e-12)), fused
+ *   with the last layer's bias (bias may be NULL) and the layout change NCHW [C][H][W] -> NHWC [H][W][C]. */
+int mccnn_bias_act(float *x, const float *bias, int N, int C, long plane, int relu, mccnn_stream_t stream);
+int mccnn_l2norm_chw_to_hwc(const float *chw, const float *bias, float *hwc, int C, int H, int W,
+                            mccnn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -233,18 +233,46 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const float *__restrict_
     out[(size_t)h * W + w] = vsum / wsum;
 }
 
-// ---- a1 epilogue: tf.nn.l2_normalize(dim=-1) (model.py:64), NCHW in -> NHWC out ---------------------------------
-// 64 pixels x C channels per workgroup through a padded LDS tile: plane rows are read in 256-B runs and each pixel's
-// C-vector is written as one contiguous run.
+// ---- a1 epilogues -------------------------------------------------------------------------------------------------
+// bias (+ ReLU) in place over an NCHW tensor: blockIdx.y = n*C + c, 4 consecutive elements per thread (planes start at
+// arbitrary 4-byte offsets, so the 16-byte accesses are declared 4-byte aligned)
+__global__ __launch_bounds__(256) void bias_act_kernel(float *__restrict__ x, const float *__restrict__ bias, int C,
+                                                       long plane, int relu)
+{
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const float b = bias[blockIdx.y % C];
+    float *p = x + (size_t)blockIdx.y * plane;
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < plane) {
+        f4u v = *reinterpret_cast<f4u *>(p + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float t = v[j] + b;
+            v[j] = relu ? fmaxf(t, 0.f) : t;
+        }
+        *reinterpret_cast<f4u *>(p + i) = v;
+    } else {
+        for (long j = i; j < plane; ++j) {
+            const float t = p[j] + b;
+            p[j] = relu ? fmaxf(t, 0.f) : t;
+        }
+    }
+}
+
+// tf.nn.l2_normalize(dim=-1) (model.py:64) of (conv output + last bias), NCHW in -> NHWC out: 64 pixels x C channels
+// per workgroup through a padded LDS tile: plane rows are read in 256-B runs and each pixel's C-vector is written as
+// one contiguous run.
 template <int C>
-__global__ __launch_bounds__(256) void l2norm_chw_to_hwc_kernel(const float *__restrict__ chw, float *__restrict__ hwc,
-                                                                long N)
+__global__ __launch_bounds__(256) void l2norm_chw_to_hwc_kernel(const float *__restrict__ chw,
+                                                                const float *__restrict__ bias,
+                                                                float *__restrict__ hwc, long N)
 {
     __shared__ float tile[C][65];
     __shared__ float scale[64];
     const long n0 = (long)blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int c = ty; c < C; c += 4) tile[c][tx] = (n0 + tx < N) ? chw[(size_t)c * N + n0 + tx] : 0.f;
+    for (int c = ty; c < C; c += 4)
+        tile[c][tx] = (n0 + tx < N) ? chw[(size_t)c * N + n0 + tx] + (bias ? bias[c] : 0.f) : 0.f;
     __syncthreads();
     if (ty == 0) {
         float s = 0.f;
@@ -336,14 +364,26 @@ extern "C" int mccnn_bilateral(const float *image, const float *disp, int H, int
     return check_launch("mccnn_bilateral");
 }
 
-extern "C" int mccnn_l2norm_chw_to_hwc(const float *chw, float *hwc, int C, int H, int W, mccnn_stream_t stream)
+extern "C" int mccnn_bias_act(float *x, const float *bias, int N, int C, long plane, int relu, mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(x && bias, MCCNN_E_INVALID, "mccnn_bias_act: null pointer");
+    MCCNN_REQUIRE(N > 0 && C > 0 && plane > 0, MCCNN_E_INVALID, "mccnn_bias_act: non-positive size");
+    MCCNN_REQUIRE((long)N * C <= 65535, MCCNN_E_UNSUPPORTED, "mccnn_bias_act: N*C=%ld exceeds grid.y", (long)N * C);
+    hipLaunchKernelGGL(bias_act_kernel, dim3(cdiv(plane, 1024), N * C), dim3(256), 0, (hipStream_t)stream, x, bias, C,
+                       plane, relu);
+    return check_launch("mccnn_bias_act");
+}
+
+extern "C" int mccnn_l2norm_chw_to_hwc(const float *chw, const float *bias, float *hwc, int C, int H, int W,
+                                       mccnn_stream_t stream)
 {
     using namespace mccnn;
     MCCNN_REQUIRE(chw && hwc, MCCNN_E_INVALID, "mccnn_l2norm_chw_to_hwc: null pointer");
     MCCNN_REQUIRE(H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_l2norm_chw_to_hwc: non-positive size");
     MCCNN_REQUIRE(C == 64, MCCNN_E_UNSUPPORTED, "mccnn_l2norm_chw_to_hwc: C=%d, built for 64 feature maps", C);
     const long N = (long)H * W;
-    hipLaunchKernelGGL((l2norm_chw_to_hwc_kernel<64>), dim3(cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, chw, hwc,
-                       N);
+    hipLaunchKernelGGL((l2norm_chw_to_hwc_kernel<64>), dim3(cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, chw, bias,
+                       hwc, N);
     return check_launch("mccnn_l2norm_chw_to_hwc");
 }

@@ -108,6 +108,18 @@ class NET(object):
             outs.append(x)
         return outs
 
+    def _convs_device(self, x):
+        """The whole-image stack on the GPU: MIOpen convolutions without bias, each followed by ONE in-place HIP pass
+        for bias + ReLU (mccnn_bias_act) instead of two elementwise launches; the last layer's bias is left to the
+        normalisation epilogue.  x: [B,1,h,w] -> [B,64,h-2n,w-2n] (contiguous)."""
+        import stereo_device
+        nl = self.num_conv_layers
+        for k in range(nl):
+            x = F.conv2d(x, self.weights[k], None)
+            if k < nl - 1:
+                x = stereo_device.bias_act_(x.contiguous(), self.biases[k], True)
+        return x.contiguous()
+
     @staticmethod
     def _l2_normalize_last(x):
         # tf.nn.l2_normalize(x, dim=-1): x * rsqrt(max(sum(x^2), 1e-12))  (model.py:64)
@@ -136,8 +148,8 @@ class NET(object):
         assert pad == self.num_conv_layers * (self.conv_kernel_size - 1) // 2, \
             "patch size must equal the receptive field so that features keep the image size"
         x = F.pad(image_hw[None, None], (pad, pad, pad, pad))  # zero-pad ONCE; every conv is VALID
-        out = self._convs_nchw(x)[-1][0].contiguous()          # [64,H,W]
-        return stereo_device.l2norm_chw_to_hwc(out)
+        out = self._convs_device(x)[0]                         # [64,H,W] without the last bias
+        return stereo_device.l2norm_chw_to_hwc(out, self.biases[-1])
 
     def features_pair_hwc(self, left_hw, right_hw):
         """Both views through the shared-weight stack as one batch of two (the Siamese towers are the same weights,
@@ -146,9 +158,9 @@ class NET(object):
         pad = (self.input_patch_size - 1) // 2
         assert pad == self.num_conv_layers * (self.conv_kernel_size - 1) // 2
         x = F.pad(torch.stack((left_hw, right_hw))[:, None], (pad, pad, pad, pad))   # [2,1,H+2p,W+2p]
-        out = self._convs_nchw(x)[-1]                                                  # [2,64,H,W]
-        return (stereo_device.l2norm_chw_to_hwc(out[0].contiguous()),
-                stereo_device.l2norm_chw_to_hwc(out[1].contiguous()))
+        out = self._convs_device(x)                                                    # [2,64,H,W], last bias pending
+        return (stereo_device.l2norm_chw_to_hwc(out[0], self.biases[-1]),
+                stereo_device.l2norm_chw_to_hwc(out[1], self.biases[-1]))
 
 
 if __name__ == "__main__":

@@ -53,12 +53,21 @@ _NO_TIMER = StageTimer(False)
 
 
 # ---- a1 ----------------------------------------------------------------------------------------------------------
-def l2norm_chw_to_hwc(chw):
-    """[C,H,W] conv output -> [H,W,C] unit feature vectors (model.py:64)."""
+def bias_act_(x, bias, relu):
+    """In place on a contiguous NCHW tensor: x = relu(x + bias[c]) (or the bias alone) in one pass (model.py:118-123)."""
+    N, C, H, W = x.shape
+    assert x.is_contiguous() and bias.numel() == C
+    hip.check(hip.load().mccnn_bias_act(hip.ptr(x), hip.ptr(bias), N, C, H * W, 1 if relu else 0, hip.stream()),
+              "mccnn_bias_act")
+    return x
+
+
+def l2norm_chw_to_hwc(chw, bias=None):
+    """[C,H,W] conv output (+ the last layer's bias) -> [H,W,C] unit feature vectors (model.py:64)."""
     C, H, W = chw.shape
     out = torch.empty((H, W, C), dtype=torch.float32, device=chw.device)
-    hip.check(hip.load().mccnn_l2norm_chw_to_hwc(hip.ptr(chw), hip.ptr(out), C, H, W, hip.stream()),
-              "mccnn_l2norm_chw_to_hwc")
+    hip.check(hip.load().mccnn_l2norm_chw_to_hwc(hip.ptr(chw), hip.ptr(bias) if bias is not None else None,
+                                                 hip.ptr(out), C, H, W, hip.stream()), "mccnn_l2norm_chw_to_hwc")
     return out
 
 
