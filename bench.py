@@ -129,12 +129,21 @@ def main():
         "sgm_pass": 2 * 2 * vol_bytes,    # one direction on BOTH volumes (one launch advances left + right)
         "sgm_first_pass": 2 * 2 * vol_bytes,
     }
+    # HBM-side bytes per launch cannot be counted live (PMC needs rocprofv3): they come from the committed PMC passes of
+    # the same kernels on the same workload (profiles/pmc_traffic.json, see profiles/r01_pmc_summary.md), else null
+    traffic = {}
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.isfile(tpath) and not args.exact:
+        with open(tpath) as f:
+            tj = json.load(f)
+        if tj.get("workload") == args.config:
+            traffic = {k: int(v["traffic_bytes"]) for k, v in tj.items() if isinstance(v, dict)}
     rooflines = {}
     for k, b in algo.items():
         if k in stages:
             ach = b / (stages[k] * 1e-3) / 1e9
             rooflines[k] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(k),
                             "launches_per_step": counts[k], "avg_launch_ms": round(stages[k], 4),
                             "algorithmic_bytes_per_launch": int(b)}
     dominant = max(rooflines, key=lambda k: per_step[k]) if rooflines else None

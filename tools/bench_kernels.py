@@ -70,6 +70,17 @@ def main():
     for name, r in (("sgm_pass_h", (0, 1)), ("sgm_pass_v", (1, 0))):
         add(name, lambda r=r: sd.sgm_pass_hwd(dl, dr, [hwd, hwd2], [0, 1], D, r, 2.3, 55.9, 4.0, 8.0, 0.08, scratch),
             4 * vol_bytes)
+    if D <= sd.SGM_FIRST_PASS_MAX_D:
+        import ctypes
+
+        def first_pass():
+            src = (ctypes.c_void_p * 2)(va.data_ptr(), vb.data_ptr())
+            dst = (ctypes.c_void_p * 2)(hwd.data_ptr(), hwd2.data_ptr())
+            sides = (ctypes.c_int * 2)(0, 1)
+            hip.check(hip.load().mccnn_sgm_first_pass(hip.ptr(dl), hip.ptr(dr), src, dst, sides, 2, D, H, W, 2.3, 55.9,
+                                                      4.0, 8.0, 0.08, hip.ptr(scratch), scratch.numel(), hip.stream()),
+                      "mccnn_sgm_first_pass")
+        add("sgm_first_pass", first_pass, 4 * vol_bytes)
     add("dhw_to_hwd", lambda: sd.dhw_to_hwd(va, hwd), 2 * vol_bytes)
     add("hwd_to_dhw", lambda: sd.hwd_to_dhw(hwd, D, vb), 2 * vol_bytes)
     add("wta", lambda: sd.wta(va), vol_bytes)
