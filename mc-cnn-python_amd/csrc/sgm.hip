@@ -330,22 +330,26 @@ __global__ __launch_bounds__(64) void sgm_first_pass_kernel(const SgmFirstParams
         return v;
     };
 
-    sgm_u32x4 ld[16];           // the tile in flight
+    // Two tiles in flight in registers.  Tiles are fetched in PAIRS (32 consecutive columns = whole 128-byte lines
+    // of every plane row): with one 16-column tile per request the second half of each line was asked for a tile
+    // later, after ~32 MB of other rows' lines had passed through the L2s, and HBM delivered every line twice
+    // (FETCH_SIZE 2.9x the algorithmic read).
+    sgm_u32x4 ld[2][16];
     uint32_t fb[TC], fa[TC];    // flags of the tile being consumed next
-    auto issue_tile = [&](int k) {      // tile k -> registers (clamped past the last tile: harmless re-read)
+    auto issue_tile = [&](int slot, int k) {      // tile k -> registers (clamped past the last tile: harmless re-read)
         const unsigned w0 = (unsigned)min(k, ntiles - 1) * TC * 4u;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) ld[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, goff[i], w0, 0);
+        for (int i = 0; i < 16; ++i) ld[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, goff[i], w0, 0);
     };
-    auto spill_tile = [&](int buf) {    // registers -> LDS [w][d]
+    auto spill_tile = [&](int slot, int buf) {    // registers -> LDS [w][d]
         float *t = tile + buf * TC * DP;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int d = 16 * i + gr;
-            t[(gc + 0) * DP + d] = __uint_as_float(ld[i].x);
-            t[(gc + 1) * DP + d] = __uint_as_float(ld[i].y);
-            t[(gc + 2) * DP + d] = __uint_as_float(ld[i].z);
-            t[(gc + 3) * DP + d] = __uint_as_float(ld[i].w);
+            t[(gc + 0) * DP + d] = __uint_as_float(ld[slot][i].x);
+            t[(gc + 1) * DP + d] = __uint_as_float(ld[slot][i].y);
+            t[(gc + 2) * DP + d] = __uint_as_float(ld[slot][i].z);
+            t[(gc + 3) * DP + d] = __uint_as_float(ld[slot][i].w);
         }
     };
     auto issue_flags = [&](int k) {     // flags of the 16 steps of tile k
@@ -357,22 +361,32 @@ __global__ __launch_bounds__(64) void sgm_first_pass_kernel(const SgmFirstParams
         }
     };
 
-    issue_tile(0);
-    spill_tile(0);
-    issue_tile(1);
+    issue_tile(0, 0);
+    issue_tile(1, 1);
+    spill_tile(0, 0);
     issue_flags(0);
     __syncthreads();
 
     float4 prev = make_float4(kInf, kInf, kInf, kInf);
     float m = 0.f;
-    for (int k = 0; k < ntiles; ++k) {
-        const float *t = tile + (k & 1) * TC * DP;
+    for (int kk = 0; kk < ntiles; kk += 2) {
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const int k = kk + par;
+        if (k >= ntiles) continue;
+        const float *t = tile + par * TC * DP;
         uint32_t cfa[TC], cfb[TC];
 #pragma unroll
         for (int c = 0; c < TC; ++c) { cfa[c] = fa[c]; cfb[c] = fb[c]; }
-        // next tile: registers -> the other LDS buffer (last read two tiles ago), then refill the registers
-        spill_tile((k + 1) & 1);
-        issue_tile(k + 2);
+        // next tile: registers -> the other LDS buffer (last read two tiles ago); an even tile then refills both
+        // register slots with the next pair
+        if (par == 0) {
+            spill_tile(1, 1);
+            issue_tile(0, k + 2);
+            issue_tile(1, k + 3);
+        } else {
+            spill_tile(0, 0);
+        }
         issue_flags(k + 1);
 #pragma unroll
         for (int c = 0; c < TC; ++c) {
@@ -420,6 +434,7 @@ __global__ __launch_bounds__(64) void sgm_first_pass_kernel(const SgmFirstParams
             m = wave_min(vmin(vmin(o.x, o.y), vmin(o.z, o.w)));
         }
         __syncthreads();   // single-wave workgroup: LDS writes of this iteration visible to the next one's reads
+      }
     }
 }
 

@@ -384,3 +384,98 @@ def test_full_size_properties_cfg2(sd):
     h = sd.dhw_to_hwd(vi)
     sd.sgm_pass_hwd(img, img, [h], [hip.MCCNN_SIDE_RIGHT], D, (0, -1), 2.0, 56.0, 4.0, 8.0, 0.08, scratch)
     assert torch.equal(sd.hwd_to_dhw(h, D)[:, :, W - 1], vi[:, :, W - 1])
+
+
+def test_full_size_cbca_streaming_vs_reference_order_cfg2(sd):
+    """750x500: the streaming (float64 prefix) kernel against the bit-exact reference-order kernel, on a plane count
+    that takes the multi-chunk launch (8 planes -> 7 row chunks) and on the single-chunk launch (256 planes, sampled).
+    Tolerance: 1e-6 per iteration on O(1) costs (the reference's own float32 summation error)."""
+    import _hipabi as hip
+    H, W = 500, 750
+    g = torch.Generator(device="cuda").manual_seed(3)
+    img = torch.rand((H, W), device="cuda", generator=g)
+    img = torch.nn.functional.avg_pool2d(img[None, None], 9, 1, 4)[0, 0].contiguous()   # smooth: long arms
+    sup = sd.cross_arms(img, 0.02, 14)
+    assert int(sd.support_count(sup).max()) > 200
+    for D, sample in ((8, slice(None)), (256, slice(0, 256, 37))):
+        v = -torch.rand((D, H, W), device="cuda", generator=g)
+        fast, _ = sd.cbca(v.clone(), torch.empty_like(v), sup, 1, 14, hip.MCCNN_CBCA_SEPARABLE)
+        vs = v[sample].contiguous()
+        ref, _ = sd.cbca(vs.clone(), torch.empty_like(vs), sup, 1, 14, hip.MCCNN_CBCA_REFERENCE_ORDER)
+        err = float((fast[sample] - ref).abs().max())
+        assert err <= 1e-6, "D=%d: streaming vs reference order differ by %g" % (D, err)
+
+
+def test_full_size_sgm_first_pass_equals_unfused_cfg2(sd):
+    """750x500x256: mccnn_sgm_first_pass (layout change fused into direction (0,1)) is bit-identical to
+    mccnn_dhw_to_hwd followed by mccnn_sgm_pass, for both sides in one launch."""
+    H, W, D = 500, 750, 256
+    g = torch.Generator(device="cuda").manual_seed(5)
+    il = torch.rand((H, W), device="cuda", generator=g)
+    ir = torch.rand((H, W), device="cuda", generator=g)
+    vl = -torch.rand((D, H, W), device="cuda", generator=g)
+    vr = -torch.rand((D, H, W), device="cuda", generator=g)
+    scratch = sd.sgm_scratch(H, W, D, vl.device)
+    hp = dict(sgm_P1=2.3, sgm_P2=55.9, sgm_Q1=4.0, sgm_Q2=8.0, sgm_D=0.08, sgm_V=1.5)
+    fused = [torch.empty((H, W, sd.hwd_pitch(D)), device="cuda") for _ in range(2)]
+    sd.sgm_average_from_dhw(il, ir, [vl, vr], fused, [0, 1], D, scratch=scratch, **hp)
+    plain = [sd.dhw_to_hwd(vl), sd.dhw_to_hwd(vr)]
+    sd.sgm_average_hwd(il, ir, plain, [0, 1], D, scratch=scratch, **hp)
+    assert torch.equal(fused[0], plain[0]) and torch.equal(fused[1], plain[1])
+
+
+def test_full_size_properties_cfg4(sd):
+    """1500x1000, D=400 (2.4 GB per volume: byte offsets beyond 2^31, D > 256 takes the two-group SGM kernel and the
+    unfused layout change): the same invariants as at cfg2."""
+    import _hipabi as hip
+    H, W, D = 1000, 1500, 400
+    g = torch.Generator(device="cuda").manual_seed(1)
+    v = -torch.rand((D, H, W), device="cuda", generator=g)
+    hwd = sd.dhw_to_hwd(v)
+    back = sd.hwd_to_dhw(hwd, D)
+    assert torch.equal(back, v)
+    del back
+    assert torch.equal(sd.wta(v), torch.argmin(v, dim=0).float())
+    img = (torch.rand((H, W), device="cuda", generator=g) * 4).round() / 4
+    sup = sd.cross_arms(img, 0.02, 14)
+    tmp = torch.empty_like(v)
+    c = torch.full_like(v, -0.375)
+    res, _ = sd.cbca(c, tmp, sup, 1, 14)
+    assert torch.equal(res, torch.full_like(res, -0.375))          # every plane, incl. those past 2^31 bytes
+    del c, res
+    res, _ = sd.cbca(v.clone(), tmp, sup, 1, 14)
+    assert res.min() >= v.min() - 1e-6 and res.max() <= v.max() + 1e-6
+    # last plane against the reference-order kernel run on that plane alone
+    last = v[D - 1:].contiguous()
+    ref, _ = sd.cbca(last.clone(), torch.empty_like(last), sup, 1, 14, hip.MCCNN_CBCA_REFERENCE_ORDER)
+    assert float((res[D - 1:] - ref).abs().max()) <= 1e-6
+    del res, tmp, ref
+    # SGM shift invariance on exactly representable costs, horizontal then vertical, D = 400
+    vi = torch.randint(0, 64, (D, H, W), device="cuda", generator=g).float()
+    scratch = sd.sgm_scratch(H, W, D, vi.device)
+    outs = []
+    for shift in (0.0, 32.0):
+        h = sd.dhw_to_hwd(vi + shift)
+        sd.sgm_pass_hwd(img, img, [h], [hip.MCCNN_SIDE_LEFT], D, (0, 1), 2.0, 56.0, 4.0, 8.0, 0.08, scratch)
+        sd.sgm_pass_hwd(img, img, [h], [hip.MCCNN_SIDE_LEFT], D, (-1, 0), 2.0, 56.0, 4.0, 8.0, 0.08, scratch)
+        outs.append(sd.hwd_to_dhw(h, D))
+        del h
+    assert torch.equal(outs[1], outs[0] + 32.0)
+
+
+def test_golden_whole_pair_fast_variants(sd, golden_cases, net_layers):
+    """The shipped default (matrix-core cost volume, streaming CBCA) on the golden pairs against the reference's final
+    map: the fast variants differ from the bit-exact ones by <= 2e-6 (cost volume) and <= 1e-6 per CBCA iteration, which
+    can flip WTA ties; tolerance = the same flip budget as the bit-exact run with the GPU's own features."""
+    import _hipabi as hip
+    from model import NET
+    net = NET(None, input_patch_size=11, batch_size=1, device="cuda").set_layers(net_layers)
+    for name, g in golden_cases:
+        D = g["cv_l"].shape[0]
+        m = sd.StereoMatcher(net, cv_mode=hip.MCCNN_CV_MFMA, cbca_order=hip.MCCNN_CBCA_SEPARABLE)
+        keep = {}
+        out = m.match(dev(g["left"]), dev(g["right"]), D, keep=keep).cpu().numpy()
+        flips = int((keep["wta"][0].cpu().numpy() != g["wta_l"]).sum())
+        close = np.isclose(out, g["bilateral"], atol=1e-3, equal_nan=True).mean()
+        assert flips <= max(2, out.size // 100), "%s: %d WTA flips" % (name, flips)
+        assert close >= 0.97, "%s: only %.3f of pixels within 1e-3 px" % (name, close)
