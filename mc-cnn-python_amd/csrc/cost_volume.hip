@@ -97,20 +97,33 @@ __global__ __launch_bounds__(256) void cost_volume_exact_kernel(const float *__r
 // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (w).  A workgroup of 4 waves covers 64 w x 64 w' and keeps only the
 // band 0 <= w-w' < D.  The accumulator is staged through LDS so that stores run along w for fixed d.
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-constexpr int CVM_LD = 66;  // LDS pitch of the 64x64 S tile (floats)
 constexpr int CVM_PL = 65;  // LDS pitch of the operand tiles: bank = (row + k) mod 32 -> conflict-free ds_read_b32
+constexpr int CVM_TP = 68;  // LDS pitch of the diagonal-major product tile T[w-x+63][w] (floats, 16-byte rows)
 
 __global__ __launch_bounds__(256) void cost_volume_mfma_kernel(const float *__restrict__ fl,
                                                                const float *__restrict__ fr, int H, int W, int D,
-                                                               float *__restrict__ lcv, float *__restrict__ rcv)
+                                                               float *__restrict__ lcv, float *__restrict__ rcv,
+                                                               int nwt, int nbands, int total)
 {
-    __shared__ float sL[64 * CVM_PL];
-    __shared__ float sR[64 * CVM_PL];
-    __shared__ float sS[64 * CVM_LD];
+    // operand tiles and, after the products are done, the diagonal-major product tile share one allocation
+    constexpr int LDS_FLOATS = (2 * 64 * CVM_PL > 127 * CVM_TP) ? 2 * 64 * CVM_PL : 127 * CVM_TP;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    float *sL = lds, *sR = lds + 64 * CVM_PL, *sT = lds;
     // tile (bw, bx): left columns w0..w0+63, right columns x0..x0+63; d = w - x in (w0-x0-63 .. w0-x0+63)
-    const int h = blockIdx.y;
-    const int w0 = blockIdx.x * 64;
-    const int x0 = w0 - (int)blockIdx.z * 64;  // blockIdx.z = band index: 0 -> x0 = w0, 1 -> x0 = w0-64, ...
+    // Work order.  The pieces of one 128-byte line of a volume row come from neighbouring tiles (the next w tile, the
+    // next band), and the dispatcher deals consecutive workgroups to the 8 XCDs round-robin - with the plain grid
+    // order every L2 ended up holding partial lines and wrote them back partially (the store phase cost 0.28 ms of
+    // 0.46).  So the launch is 1-D and each XCD gets a contiguous range of (row, band, w tile) work items: all
+    // tiles of an image row meet in one L2 and lines leave it whole.  (Placement only affects speed.)
+    int id;
+    {
+        const int b = blockIdx.x, qq = total >> 3, r = total & 7, xc = b & 7;
+        id = (xc < r ? xc * (qq + 1) : r * (qq + 1) + (xc - r) * qq) + (b >> 3);
+    }
+    const int wt = id % nwt, band = (id / nwt) % nbands;
+    const int h = id / (nwt * nbands);
+    const int w0 = wt * 64;
+    const int x0 = w0 - band * 64;  // band 0 -> x0 = w0, 1 -> x0 = w0-64, ...
     if (x0 + 63 < 0) return;
     if (w0 - x0 - 63 >= D) return;
     const int tid = threadIdx.x;
@@ -135,52 +148,74 @@ __global__ __launch_bounds__(256) void cost_volume_mfma_kernel(const float *__re
     const float *pb = &sR[(wc + (lane & 31)) * CVM_PL + (lane >> 5)];
 #pragma unroll
     for (int k = 0; k < CV_C; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k], pb[k], acc, 0, 0, 0);
+    __syncthreads();   // every wave is done with the operand tiles: their LDS becomes the product tile
+    // Products go to LDS diagonal-major, already negated: T[w - x + 63][w].  A row of T is one disparity d = dbase +
+    // (row - 63) and runs along w, which is how both volumes are written (lcv[d][h][w] and rcv[d][h][w - d]).
 #pragma unroll
     for (int rg = 0; rg < 16; ++rg) {
-        const int row = (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
-        sS[(wr + row) * CVM_LD + wc + (lane & 31)] = acc[rg];
+        const int row = wr + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
+        const int col = wc + (lane & 31);
+        sT[(row - col + 63) * CVM_TP + row] = -1.f * acc[rg];
     }
     __syncthreads();
-    // Store along w for fixed d: 127 diagonals of the 64x64 tile; thread t walks diagonal-major so that
-    // consecutive lanes write consecutive w (and consecutive w' = w - d).
     const size_t plane = (size_t)H * W;
     const int dbase = w0 - x0;  // d of the main diagonal
-    // The vector-memory pipe costs the same per wave instruction whatever its width, so a lane stores 4 consecutive w
-    // (16 B, dword aligned) and one instruction covers 4 diagonals x 16 quads; the quads cut by the two ends of a
-    // diagonal fall back to scalar stores.
+    // (1) whole quads: a lane stores 4 consecutive w of one diagonal (16 B, dword aligned) to both volumes - the
+    // vector-memory pipe costs about the same per wave instruction whatever its width; one instruction covers 4
+    // diagonals x 16 quads.  Quads cut by an end of the diagonal (the tile border in x) are left to pass (2), so
+    // this loop has no per-element path except at the right image border.
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
     const int q = lane & 15, sub = lane >> 4;
     for (int dg = wave; dg < 32; dg += 4) {
         const int diag = dg * 4 + sub;
-        if (diag >= 127) continue;
         const int dd = diag - 63;      // w_local - x_local
         const int d = dbase + dd;
-        if (d < 0 || d >= D) continue;
         const int wl = 4 * q;          // first w_local of this lane's quad
         const int xl = wl - dd;        // matching x_local
-        if (xl + 3 < 0 || xl >= 64) continue;
         const int w = w0 + wl, x = x0 + xl;
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int xj = min(max(xl + j, 0), 63);
-            v[j] = -1.f * sS[(wl + j) * CVM_LD + xj];
-        }
+        if (diag >= 127 || d < 0 || d >= D || xl < 0 || xl + 3 > 63 || w >= W) continue;
+        const float4 t = *reinterpret_cast<const float4 *>(&sT[diag * CVM_TP + wl]);
         float *pl = lcv + (size_t)d * plane + rowbase + w;
         float *pr = rcv + (size_t)d * plane + rowbase + x;
-        if (xl >= 0 && xl + 3 < 64 && w + 3 < W && x >= 0) {
-            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        if (w + 3 < W) {
             f4u o;
-            o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+            o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
             *reinterpret_cast<f4u *>(pl) = o;
             *reinterpret_cast<f4u *>(pr) = o;
         } else {
+            const float v[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (xl + j >= 0 && xl + j < 64 && w + j < W && x + j >= 0) {
+                if (w + j < W) {
                     pl[j] = v[j];
                     pr[j] = v[j];
                 }
         }
+    }
+    // (2) the ragged end of each diagonal: at most 3 elements, at the end where the diagonal leaves the tile through
+    // x_local = 0 (dd > 0, its first elements) or x_local = 63 (dd < 0, its last elements)
+    for (int i = tid; i < 127 * 3; i += 256) {
+        const int diag = i / 3, j = i - diag * 3;
+        const int dd = diag - 63;
+        const int d = dbase + dd;
+        if (dd == 0 || d < 0 || d >= D) continue;
+        int wl;
+        if (dd > 0) {
+            const int r = dd & 3;              // the quad holding w_local = dd starts r elements earlier
+            if (r == 0 || j >= 4 - r) continue;
+            wl = dd + j;
+        } else {
+            const int e = 63 + dd;             // last element of the diagonal
+            const int cnt = (e & 3) + 1;
+            if (cnt == 4 || j >= cnt) continue;
+            wl = e - j;
+        }
+        const int xl = wl - dd;
+        const int w = w0 + wl, x = x0 + xl;
+        if (w >= W || x < 0) continue;
+        const float v = sT[diag * CVM_TP + wl];
+        lcv[(size_t)d * plane + rowbase + w] = v;
+        rcv[(size_t)d * plane + rowbase + x] = v;
     }
 }
 
@@ -257,8 +292,11 @@ extern "C" int mccnn_cost_volume(const float *fl, const float *fr, int H, int W,
         const dim3 grid(cdiv(W, CV_TW), H, cdiv(D, CV_DT));
         hipLaunchKernelGGL(cost_volume_exact_kernel, grid, block, 0, s, fl, fr, H, W, D, lcv, rcv);
     } else if (mode == MCCNN_CV_MFMA) {
-        const dim3 grid(cdiv(W, 64), H, cdiv(D + 63, 64) + 1);
-        hipLaunchKernelGGL(cost_volume_mfma_kernel, grid, block, 0, s, fl, fr, H, W, D, lcv, rcv);
+        const int nwt = cdiv(W, 64), nbands = cdiv(D + 63, 64) + 1;
+        const long total = (long)nwt * nbands * H;
+        MCCNN_REQUIRE(total <= 0x7fffffffL, MCCNN_E_UNSUPPORTED, "mccnn_cost_volume: %ld tiles exceed the grid", total);
+        hipLaunchKernelGGL(cost_volume_mfma_kernel, dim3((unsigned)total), block, 0, s, fl, fr, H, W, D, lcv, rcv, nwt,
+                           nbands, (int)total);
     } else {
         MCCNN_REQUIRE(false, MCCNN_E_INVALID, "mccnn_cost_volume: unknown mode %d", mode);
     }
