@@ -284,9 +284,9 @@ struct SgmFirstParams {
 template <bool FULL>
 __global__ __launch_bounds__(64) void sgm_first_pass_kernel(const SgmFirstParams P)
 {
-    constexpr int TC = 16;          // columns per tile
-    constexpr int DP = 260;         // LDS pitch of one tile column (floats): 16-byte aligned, 2-way conflicts on the writes
-    __shared__ __attribute__((aligned(16))) float tile[2 * TC * DP];
+    constexpr int TC = 32;          // columns per tile: 128 bytes of every plane row = whole cache lines
+    constexpr int DP = 260;         // LDS pitch of one tile column (floats): 16-byte aligned rows
+    __shared__ __attribute__((aligned(16))) float tile[TC * DP];
     const SgmFirstJob J = P.job[blockIdx.y];
     const int lane = threadIdx.x;
     const int h = blockIdx.x;
@@ -312,12 +312,14 @@ __global__ __launch_bounds__(64) void sgm_first_pass_kernel(const SgmFirstParams
     const int voff = act ? 4 * dl : kDrop;                                   // HWD vector of this lane
     const int boff = act ? P.pad + (J.dsign > 0 ? dl : -dl - 3) : kDrop;     // packed B flags
     const int shl = J.dsign > 0 ? 0 : 24, sdir = J.dsign > 0 ? 8 : -8;
-    // tile gather: instruction i covers plane rows d = 16 i + (lane >> 2), columns 4 (lane & 3) .. +3
-    const int gr = lane >> 2, gc = (lane & 3) * 4;
-    unsigned goff[16];
+    // Tile gather: instruction i covers plane rows d = 8 i + (lane >> 3), columns 4 (lane & 7) .. +3 - eight lanes
+    // share one 128-byte line, so an instruction asks for 8 whole lines (the 16-column tiles of the first version
+    // asked for 64 half lines per instruction and ran into the vector-memory pipe: 0.47 ms).
+    const int gr = lane >> 3, gc = (lane & 7) * 4;
+    unsigned goff[32];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int d = 16 * i + gr;
+    for (int i = 0; i < 32; ++i) {
+        const int d = 8 * i + gr;
         goff[i] = d < D ? (unsigned)((size_t)d * plane * 4) + 4u * gc : (unsigned)kDrop;
     }
     auto mask_tail = [&](float4 v) {
@@ -330,29 +332,28 @@ __global__ __launch_bounds__(64) void sgm_first_pass_kernel(const SgmFirstParams
         return v;
     };
 
-    // Two tiles in flight in registers.  Tiles are fetched in PAIRS (32 consecutive columns = whole 128-byte lines
-    // of every plane row): with one 16-column tile per request the second half of each line was asked for a tile
-    // later, after ~32 MB of other rows' lines had passed through the L2s, and HBM delivered every line twice
-    // (FETCH_SIZE 2.9x the algorithmic read).
-    sgm_u32x4 ld[2][16];
-    uint32_t fb[TC], fa[TC];    // flags of the tile being consumed next
-    auto issue_tile = [&](int slot, int k) {      // tile k -> registers (clamped past the last tile: harmless re-read)
+    // One tile lives in LDS (being consumed, 32 steps) while the next one is in flight in registers; when the LDS
+    // tile is used up the registers are spilled over it.  33 KB of LDS per wave = 4 waves per CU, as many scanline
+    // waves as a 750x500 pair offers per CU anyway (1000 waves on 256 CUs).
+    sgm_u32x4 ld[32];
+    auto issue_tile = [&](int k) {      // tile k -> registers (clamped past the last tile: harmless re-read)
         const unsigned w0 = (unsigned)min(k, ntiles - 1) * TC * 4u;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) ld[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, goff[i], w0, 0);
+        for (int i = 0; i < 32; ++i) ld[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, goff[i], w0, 0);
     };
-    auto spill_tile = [&](int slot, int buf) {    // registers -> LDS [w][d]
-        float *t = tile + buf * TC * DP;
+    auto spill_tile = [&]() {           // registers -> LDS [w][d]
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int d = 16 * i + gr;
-            t[(gc + 0) * DP + d] = __uint_as_float(ld[slot][i].x);
-            t[(gc + 1) * DP + d] = __uint_as_float(ld[slot][i].y);
-            t[(gc + 2) * DP + d] = __uint_as_float(ld[slot][i].z);
-            t[(gc + 3) * DP + d] = __uint_as_float(ld[slot][i].w);
+        for (int i = 0; i < 32; ++i) {
+            const int d = 8 * i + gr;
+            tile[(gc + 0) * DP + d] = __uint_as_float(ld[i].x);
+            tile[(gc + 1) * DP + d] = __uint_as_float(ld[i].y);
+            tile[(gc + 2) * DP + d] = __uint_as_float(ld[i].z);
+            tile[(gc + 3) * DP + d] = __uint_as_float(ld[i].w);
         }
     };
-    auto issue_flags = [&](int k) {     // flags of the 16 steps of tile k
+
+    uint32_t fb[TC], fa[TC];    // flags of the tile consumed next
+    auto issue_flags = [&](int k) {
 #pragma unroll
         for (int c = 0; c < TC; ++c) {
             const unsigned w = (unsigned)min(k * TC + c, W - 1);
@@ -361,48 +362,35 @@ __global__ __launch_bounds__(64) void sgm_first_pass_kernel(const SgmFirstParams
         }
     };
 
-    issue_tile(0, 0);
-    issue_tile(1, 1);
-    spill_tile(0, 0);
+    issue_tile(0);
     issue_flags(0);
-    __syncthreads();
-
     float4 prev = make_float4(kInf, kInf, kInf, kInf);
     float m = 0.f;
-    for (int kk = 0; kk < ntiles; kk += 2) {
+    for (int k = 0; k < ntiles; ++k) {
+        uint32_t cfa_[TC], cfb_[TC];
 #pragma unroll
-      for (int par = 0; par < 2; ++par) {
-        const int k = kk + par;
-        if (k >= ntiles) continue;
-        const float *t = tile + par * TC * DP;
-        uint32_t cfa[TC], cfb[TC];
-#pragma unroll
-        for (int c = 0; c < TC; ++c) { cfa[c] = fa[c]; cfb[c] = fb[c]; }
-        // next tile: registers -> the other LDS buffer (last read two tiles ago); an even tile then refills both
-        // register slots with the next pair
-        if (par == 0) {
-            spill_tile(1, 1);
-            issue_tile(0, k + 2);
-            issue_tile(1, k + 3);
-        } else {
-            spill_tile(0, 0);
-        }
+        for (int c = 0; c < TC; ++c) { cfa_[c] = fa[c]; cfb_[c] = fb[c]; }
+        __syncthreads();   // single-wave workgroup: the previous tile's LDS reads are done
+        spill_tile();
+        issue_tile(k + 1);
         issue_flags(k + 1);
+        __syncthreads();
 #pragma unroll
         for (int c = 0; c < TC; ++c) {
             const int w = k * TC + c;
             if (w >= W) continue;
-            const float4 cv = mask_tail(*reinterpret_cast<const float4 *>(&t[c * DP + dl]));
+            const uint32_t cfa = cfa_[c], cfb = cfb_[c];
+            const float4 cv = mask_tail(*reinterpret_cast<const float4 *>(&tile[c * DP + dl]));
             float4 o;
             if (w == 0) {
                 o = cv;     // the first line of the scan is untouched (it only seeds the recurrence)
             } else {
-                const int a = __builtin_amdgcn_readfirstlane((int)cfa[c]);
+                const int a = __builtin_amdgcn_readfirstlane((int)cfa);
                 const float p1lo = a ? P.p1[1] : P.p1[0], p1hi = a ? P.p1[2] : P.p1[1];
                 const float p2lo = a ? P.p2[1] : P.p2[0], p2hi = a ? P.p2[2] : P.p2[1];
                 const float below = dpp_mov<0x138>(kInf, prev.w);
                 const float above = dpp_mov<0x130>(kInf, prev.x);
-                const uint32_t f = cfb[c];
+                const uint32_t f = cfb;
                 const bool b0 = (f >> shl) & 1u, b1 = (f >> (shl + sdir)) & 1u, b2 = (f >> (shl + 2 * sdir)) & 1u,
                            b3 = (f >> (shl + 3 * sdir)) & 1u;
                 {
@@ -433,8 +421,6 @@ __global__ __launch_bounds__(64) void sgm_first_pass_kernel(const SgmFirstParams
             prev = o;
             m = wave_min(vmin(vmin(o.x, o.y), vmin(o.z, o.w)));
         }
-        __syncthreads();   // single-wave workgroup: LDS writes of this iteration visible to the next one's reads
-      }
     }
 }
 

@@ -41,9 +41,12 @@ def main():
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--shape", default="", help="H,W,D instead of a named config (scaling experiments)")
     args = ap.parse_args()
     hip.require_device()
     H, W, D = CONFIGS[args.config]
+    if args.shape:
+        H, W, D = (int(x) for x in args.shape.split(","))
     only = set(x for x in args.only.split(",") if x)
     L, R, _, _, _ = synthetic.make_pair(H, W, D, seed=100)
     dl, dr = torch.from_numpy(L[:, :, 0]).cuda(), torch.from_numpy(R[:, :, 0]).cuda()
