@@ -13,6 +13,10 @@
 //   cbca_iter_kernel    LDS-tiled; REFERENCE_ORDER variant walks the region in the reference's list order and is
 //                       bit-exact; its separable variant serves distances > 14.
 #include "common.h"
+#ifndef PRIO_EMIT
+#define PRIO_EMIT 3
+#define PRIO_HSUM 2
+#endif
 
 namespace mccnn {
 
@@ -329,9 +333,9 @@ __global__ __launch_bounds__(256) void cbca_pipe_kernel(const float *__restrict_
 
     if (threadIdx.x < 2 * B) prow[threadIdx.x * PRP] = 0.0;
     if (wave == 1 && rl) {                     // Q of the row above the first staged row is zero
-        double *z = &ring[((ys - 1 + RING) % RING) * RP + 2 * lane];
+        double *z = &ring[((ys - 1 + RING) % RING) * RP + lane];
         z[0] = 0.0;
-        z[1] = 0.0;
+        z[RP / 2] = 0.0;
     }
 
     if (wave == 0 || wave == 3) {
@@ -386,6 +390,7 @@ __global__ __launch_bounds__(256) void cbca_pipe_kernel(const float *__restrict_
         }
     } else if (wave == 1) {
         // ---------------- hsum role: batch t-1 ----------------
+        __builtin_amdgcn_s_setprio(PRIO_HSUM);
         double q0 = 0.0, q1 = 0.0;
         u32x2 sy[NPF][B];
         auto issue = [&](int slot, int k) {
@@ -430,11 +435,10 @@ __global__ __launch_bounds__(256) void cbca_pipe_kernel(const float *__restrict_
                         const int y = ys + k * B + b;
                         q0 += hs0[b];
                         q1 += hs1[b];
-                        if (rl) {
-                            double2 qq;
-                            qq.x = q0;
-                            qq.y = q1;
-                            *reinterpret_cast<double2 *>(&ring[(y % RING) * RP + 2 * lane]) = qq;
+                        if (rl) {   // even column -> slot lane, odd column -> slot RP/2 + lane
+                            double *rr = &ring[(y % RING) * RP + lane];
+                            rr[0] = q0;
+                            rr[RP / 2] = q1;
                         }
                     }
                     issue(slot, k + NPF);
@@ -444,6 +448,7 @@ __global__ __launch_bounds__(256) void cbca_pipe_kernel(const float *__restrict_
         }
     } else {
         // ---------------- emit role: batch t-2 ----------------
+        __builtin_amdgcn_s_setprio(PRIO_EMIT);
         constexpr int EB = B;      // (splitting the rows over two emit waves, 320-thread workgroups, measured slower)
         constexpr int e0 = 0;
         constexpr int kDrop = 0x7ffffff0;          // byte offset past every plane: the range check drops the store
@@ -470,7 +475,7 @@ __global__ __launch_bounds__(256) void cbca_pipe_kernel(const float *__restrict_
                     // indices and their store is dropped by an out-of-range buffer offset.
                     double qa0[EB], qb0[EB], qa1[EB], qb1[EB];
                     const char *ringb = reinterpret_cast<const char *>(ring);
-                    const unsigned colb = 16u * (unsigned)lane;          // byte offset of column 2*lane in a ring row
+                    const unsigned colb = 8u * (unsigned)lane;           // byte offset of this lane's even column in a ring row
 #pragma unroll
                     for (int b = 0; b < EB; ++b) {
                         const int yoc = min(max(ys + k * B + e0 + b - R, h0), h1 - 1);
@@ -486,8 +491,8 @@ __global__ __launch_bounds__(256) void cbca_pipe_kernel(const float *__restrict_
                         };
                         qa0[b] = *reinterpret_cast<const double *>(ringb + above(arm_down(a)) + colb);
                         qb0[b] = *reinterpret_cast<const double *>(ringb + below(arm_up(a)) + colb);
-                        qa1[b] = *reinterpret_cast<const double *>(ringb + above(arm_down(c)) + colb + 8);
-                        qb1[b] = *reinterpret_cast<const double *>(ringb + below(arm_up(c)) + colb + 8);
+                        qa1[b] = *reinterpret_cast<const double *>(ringb + above(arm_down(c)) + colb + 4 * RP);
+                        qb1[b] = *reinterpret_cast<const double *>(ringb + below(arm_up(c)) + colb + 4 * RP);
                     }
 #pragma unroll
                     for (int b = 0; b < EB; ++b) {
