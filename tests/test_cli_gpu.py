@@ -1,0 +1,61 @@
+"""GPU: the match.py drop-in end to end on files - the reference's command line (match.py:14-46), its directory
+layout and output files (match.py:99-110, 182-184), checked against the CPU checker fed the same decoded images."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_pair(dirname, H, W, ndisp, seed):
+    from PIL import Image
+    import synthetic
+    os.makedirs(dirname)
+    L, R, _, _, _ = synthetic.make_pair(H, W, ndisp, seed=seed)
+    for name, img in (("im0.png", L), ("im1.png", R)):
+        g = img[:, :, 0]
+        g8 = np.clip((g - g.min()) / (g.max() - g.min()) * 255.0, 0, 255).astype(np.uint8)
+        Image.fromarray(g8, mode="L").save(os.path.join(dirname, name))
+    with open(os.path.join(dirname, "calib.txt"), "w") as f:
+        f.write("cam0=[1 0 0; 0 1 0; 0 0 1]\ncam1=[1 0 0; 0 1 0; 0 0 1]\ndoffs=0\nbaseline=100\n"
+                "width=%d\nheight=%d\nndisp=%d\nisint=0\nvmin=0\nvmax=%d\ndyavg=0\ndymax=0\n" % (W, H, ndisp, ndisp))
+
+
+def test_match_cli_writes_reference_outputs(tmp_path, net_layers):
+    import oracle as o
+    import util
+    data = tmp_path / "data"
+    out = tmp_path / "out"
+    H, W, D = 40, 64, 16
+    rels = ["trainingH/pairA", "trainingH/pairB"]
+    for i, rel in enumerate(rels):
+        _write_pair(str(data / rel), H, W, D, seed=20 + i)
+    lst = tmp_path / "list.txt"
+    lst.write_text("".join("%s/im0.png\n" % (data / rel) for rel in rels))
+    cmd = [sys.executable, os.path.join(ROOT, "mc-cnn-python_amd", "src", "match.py"), "-g", "0",
+           "--list_file", str(lst), "--resume", os.path.join(GOLDEN_DIR, "mccnn_fast_weights.npz"),
+           "--data_dir", str(data), "--save_dir", str(out), "-t", "t1", "-s", "0", "-e", "1", "--exact"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    for rel in rels:
+        res = out / "submit_t1" / rel
+        img = out / "submit_t1_imgs" / rel
+        assert (res / "disp0MCCNN.pfm").is_file() and (res / "timeMCCNN.txt").is_file()
+        assert (img / "disp0MCCNN.pgm").is_file()
+        assert float((res / "timeMCCNN.txt").read_text().strip()) > 0.0
+        disp = util.readPfm(str(res / "disp0MCCNN.pfm"))
+        disp = disp[0] if isinstance(disp, tuple) else disp
+        disp = np.asarray(disp, np.float32).reshape(H, W)
+        # the same decode + standardisation as match.py:118-123, then the CPU checker's whole timed region
+        imgs = []
+        for name in ("im0.png", "im1.png"):
+            g = util.read_gray(str(data / rel / name)).astype(np.float32)
+            imgs.append(np.expand_dims((g - np.mean(g, axis=(0, 1))) / np.std(g, axis=(0, 1)), 2))
+        want = o.match_pair(imgs[0], imgs[1], D, net_layers)
+        close = np.isclose(disp, want, atol=1e-3, equal_nan=True).mean()
+        assert close >= 0.97, "%s: only %.3f of pixels within 1e-3 px of the CPU checker" % (rel, close)
