@@ -3,13 +3,13 @@
 //
 // The reference materialises, per pixel, the coordinate list of its cross-shaped support region (int32
 // [H,W,784,2], 2.35 GB per image at 750x500) and then gathers through it.  Here a pixel carries
-// one packed 32-bit word (four 5-bit arm lengths + the 12-bit region size, mccnn_support_t); the region is
-// regenerated from the arms.
+// one packed 32-bit word (four 5-bit arm lengths + the 12-bit region size, mccnn_support_t) plus one derived 8-byte
+// "emit word" (reciprocal of the size + vertical arms); the region is regenerated from the arms.
 //
 // Two aggregation kernels, same result set:
 //   cbca_pipe_kernel    (MCCNN_CBCA_SEPARABLE, default distance) - O(1) work per output via float64 prefix sums,
-//                       four wave-specialised stages stream a column strip of one disparity plane; bound by the
-//                       vector-memory issue rate and HBM (8 B/voxel/iteration).
+//                       four wave-specialised stages stream a column strip of one disparity plane; 8 B/voxel/iteration
+//                       of HBM traffic, bound by the latency of a pipeline step (TA, VALU and LDS all ~50-60 % busy).
 //   cbca_iter_kernel    LDS-tiled; REFERENCE_ORDER variant walks the region in the reference's list order and is
 //                       bit-exact; its separable variant serves distances > 14.
 #include "common.h"
@@ -240,15 +240,20 @@ static int launch_cbca(const float *in, float *out, const Support *sup, int D, i
 //                    wave  1    hsum   batch t-1   prow lookups, column prefix -> ring rows
 //                    wave  2    emit   batch t-2   ring lookups, x 1/|U|, store
 // 16 waves per CU, and a strip advances at the pace of its slowest stage instead of the sum of all three (measured
-// alone at 750x500x256: scan 0.14 ms, hsum 0.16 ms, emit 0.28 ms; a fifth wave sharing the emit rows was slower).
+// alone at 750x500x256: scan 0.14 ms, hsum 0.16 ms, emit 0.21 ms; a fifth wave sharing the emit rows, one scan + two
+// emit waves, and 8-row batches were all slower).  Roles take s_setprio emit > hsum > scan: the emit wave is the one
+// that never waits at the barrier.
 //
-// Memory side.  The vector-memory (TA) pipe is what this kernel saturates (TA busy 72 % with 8-byte support records),
-// so each row moves with four 8-byte-per-lane instructions: the 2 floats, the packed support words of the staged row
-// and of the emitted row (2 pixels each), and the 2-float store - all raw buffer ops: per-lane byte offset +
-// wave-uniform row offset, no address arithmetic.  Every access stays inside its plane by construction (the buffer range
-// check does not cover the scalar row offset): pairs entirely outside the image are clamped onto valid columns - no arm
-// can reach those elements, so any finite value cancels in the prefix differences - and the one pair that can straddle
-// the right edge (odd W) is fetched one column early and swizzled.
+// Memory side.  The vector-memory (TA) pipe is the busiest unit (a wave instruction keeps it ~16 cycles + bytes/64),
+// so a row moves with four instructions: the 2 floats per lane (8 B), the packed support words of the staged row
+// (8 B: left/right arms of 2 pixels), the emit words of the leaving row (16 B: float64 reciprocal of the region size
+// with the vertical arms in its low mantissa bits, 2 pixels) and the 2-float store - all raw buffer ops: per-lane byte
+// offset + wave-uniform row offset, no address arithmetic.  Each descriptor spans one whole plane and every access
+// stays inside it by construction (the range check tests voffset + soffset against that span, per dword at the high
+// end; tools/probe/bufrange.hip): pairs entirely outside the image are clamped onto valid columns - no arm can reach
+// those elements, so any finite value cancels in the prefix differences - the one pair that can straddle the right
+// edge (odd W) is fetched one column early and swizzled, and stores of rows outside the chunk are dropped by a
+// per-lane offset beyond the span instead of a branch.
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ double dpp_f64(double x)
 {
