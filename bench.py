@@ -81,8 +81,15 @@ def main():
     from model import NET
 
     hip.require_device()  # raises without a GPU or without the built library: no fallback
-    torch.cuda.set_device(local_rank)
-    mgpu.init("nccl", torch.device("cuda", local_rank))   # RCCL; only the barrier + timing all_gather use it
+    # MCCNN_BENCH_SHARED_GPU=1 (tests only): ranks share the visible GPUs round-robin and rendezvous over gloo, so the
+    # N > 1 control flow of this file can run on a one-GPU box; RCCL refuses two ranks on one device
+    shared = os.environ.get("MCCNN_BENCH_SHARED_GPU") == "1"
+    device_index = local_rank % torch.cuda.device_count() if shared else local_rank
+    torch.cuda.set_device(device_index)
+    if shared:
+        mgpu.init("gloo")
+    else:
+        mgpu.init("nccl", torch.device("cuda", device_index))   # RCCL; only the barrier + timing all_gather use it
 
     H, W, D = CONFIGS[args.config]
     wpath = os.path.join(ROOT, "tests", "golden", "mccnn_fast_weights.npz")

@@ -59,3 +59,24 @@ def test_match_cli_writes_reference_outputs(tmp_path, net_layers):
         want = o.match_pair(imgs[0], imgs[1], D, net_layers)
         close = np.isclose(disp, want, atol=1e-3, equal_nan=True).mean()
         assert close >= 0.97, "%s: only %.3f of pixels within 1e-3 px of the CPU checker" % (rel, close)
+
+
+def test_bench_two_ranks_share_one_gpu():
+    """bench.py's N > 1 path as the driver launches it (torch.distributed.run, one process per rank), on a one-GPU
+    box: the two ranks share the GPU and rendezvous over gloo (MCCNN_BENCH_SHARED_GPU=1).  Rank 0 prints ONE JSON
+    line with the whole-job rate over the slower rank's time."""
+    import json
+    env = dict(os.environ, MCCNN_BENCH_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--config", "cfg1"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["unit"] == "Mdisparities/s" and d["cpu_baseline"] is None
+    # value = 2 ranks x 256*256*64 voxels x 3 steps / (max-rank seconds): consistent with ms_per_step
+    want = 2 * 256 * 256 * 64 * 1e-6 / (d["ms_per_step"] * 1e-3)
+    assert abs(d["value"] - want) <= 0.02 * want
