@@ -18,6 +18,9 @@ MCCNN_CBCA_SEPARABLE = 0
 MCCNN_CBCA_REFERENCE_ORDER = 1
 MCCNN_SIDE_LEFT = 0
 MCCNN_SIDE_RIGHT = 1
+MCCNN_E_INVALID = -1      # include/mccnn.h: bad argument
+MCCNN_E_UNSUPPORTED = -2  # shape / parameter the kernels are not built for
+MCCNN_E_SCRATCH = -3      # scratch buffer too small
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int

@@ -479,3 +479,84 @@ def test_golden_whole_pair_fast_variants(sd, golden_cases, net_layers):
         close = np.isclose(out, g["bilateral"], atol=1e-3, equal_nan=True).mean()
         assert flips <= max(2, out.size // 100), "%s: %d WTA flips" % (name, flips)
         assert close >= 0.97, "%s: only %.3f of pixels within 1e-3 px" % (name, close)
+
+
+def _random_shapes(n, seed):
+    """Seeded ragged shapes: odd and even widths, single-strip and multi-strip images, heights below one row batch and
+    above one row chunk, D down to 2 and not a multiple of 4; volumes small enough for the CPU checker."""
+    rng = np.random.default_rng(seed)
+    shapes = []
+    while len(shapes) < n:
+        H = int(rng.integers(3, 150))
+        W = int(rng.integers(8, 420))
+        D = int(rng.integers(2, min(W - 2, 260) + 1))
+        if H * W * D <= 2_500_000:
+            shapes.append((H, W, D))
+    return shapes
+
+
+@pytest.mark.parametrize("H,W,D", _random_shapes(10, seed=2024))
+def test_oracle_random_shapes_fast_and_exact_kernels(pf, sd, H, W, D):
+    """Every volume kernel against the CPU checker on seeded ragged shapes (the fixed cases above pick the shapes by
+    hand; these are drawn): cost volume in both modes, both aggregation orders (one launch configuration per shape:
+    strips, row chunks, odd-width instantiation), SGM_average through the fused first pass."""
+    import oracle as o
+    import synthetic
+    rng = np.random.default_rng(H * 7919 + W * 31 + D)
+    L, R, _, _, _ = synthetic.make_pair(H, W, max(D, 4), seed=H + W + D)
+    # cost volume
+    fl = rng.standard_normal((H, W, 64)).astype(np.float32)
+    fr = rng.standard_normal((H, W, 64)).astype(np.float32)
+    fl /= np.linalg.norm(fl, axis=-1, keepdims=True)
+    fr /= np.linalg.norm(fr, axis=-1, keepdims=True)
+    ol, orr = o.compute_cost_volume(fl, fr, D)
+    pf.COST_VOLUME_MODE = "exact"
+    gl, gr = pf.compute_cost_volume(fl, fr, D)
+    assert_bits(gl, ol, "cost volume L exact %dx%dx%d" % (H, W, D))
+    assert_bits(gr, orr, "cost volume R exact %dx%dx%d" % (H, W, D))
+    pf.COST_VOLUME_MODE = "mfma"
+    try:
+        ml, mr = pf.compute_cost_volume(fl, fr, D)
+    finally:
+        pf.COST_VOLUME_MODE = "exact"
+    assert np.abs(ml - ol).max() <= 2e-6 and np.abs(mr - orr).max() <= 2e-6, (H, W, D)
+    # aggregation: reference order bit-exact, streaming kernel within the stated tolerance
+    cl, cr = o.cost_volume_aggregation(L, R, ol, orr, 0.02, 14, 2)
+    pf.CBCA_ORDER = "reference"
+    try:
+        rl, rr = pf.cost_volume_aggregation(L, R, ol, orr, 0.02, 14, 2)
+    finally:
+        pf.CBCA_ORDER = "separable"
+    assert_bits(rl, cl, "cbca reference order L %dx%dx%d" % (H, W, D))
+    assert_bits(rr, cr, "cbca reference order R %dx%dx%d" % (H, W, D))
+    sl, sr = pf.cost_volume_aggregation(L, R, ol, orr, 0.02, 14, 2)
+    assert np.abs(sl - cl).max() <= 2e-6 and np.abs(sr - cr).max() <= 2e-6, (H, W, D)
+    # SGM_average (fused first pass when D <= 256) is bit-exact
+    if D >= 2:
+        al, ar = o.SGM_average(cl.copy(), cr.copy(), L, R, 2.3, 55.9, 4, 8, 0.08, 1.5)
+        bl, br = pf.SGM_average(cl.copy(), cr.copy(), L, R, 2.3, 55.9, 4, 8, 0.08, 1.5)
+        assert_bits(bl, al, "SGM_average L %dx%dx%d" % (H, W, D))
+        assert_bits(br, ar, "SGM_average R %dx%dx%d" % (H, W, D))
+
+
+def test_abi_error_behaviour(sd):
+    """Bad arguments come back as MCCNN_E_* with a message, never as a launch: null pointers, in-place aggregation,
+    distances / disparity ranges the kernels are not built for."""
+    import _hipabi as hip
+    lib = hip.load()
+    v = torch.zeros((4, 8, 16), device="cuda")
+    img = torch.zeros((8, 16), device="cuda")
+    sup = sd.cross_arms(img, 0.02, 14)
+    s = hip.stream()
+    assert lib.mccnn_cbca_iter(hip.ptr(v), hip.ptr(v), hip.ptr(sup), 4, 8, 16, 14, 0, s) == hip.MCCNN_E_INVALID
+    assert b"in-place" in lib.mccnn_last_error_string()
+    assert lib.mccnn_cbca_iter(None, hip.ptr(v), hip.ptr(sup), 4, 8, 16, 14, 0, s) == hip.MCCNN_E_INVALID
+    out = torch.empty_like(v)
+    assert lib.mccnn_cbca_iter(hip.ptr(v), hip.ptr(out), hip.ptr(sup), 4, 8, 16, 40, 0, s) == hip.MCCNN_E_UNSUPPORTED
+    assert lib.mccnn_cbca_iter(hip.ptr(v), hip.ptr(out), hip.ptr(sup), 4, 8, 16, 14, 7, s) == hip.MCCNN_E_INVALID
+    assert lib.mccnn_cross_arms(hip.ptr(img), 8, 16, 0.02, 33, hip.ptr(sup), s) == hip.MCCNN_E_UNSUPPORTED
+    assert lib.mccnn_wta(hip.ptr(v), 0, 8, 16, hip.ptr(img), s) == hip.MCCNN_E_INVALID
+    with pytest.raises(hip.MccnnHipError):
+        hip.check(lib.mccnn_wta(None, 4, 8, 16, hip.ptr(img), s), "mccnn_wta")
+    with pytest.raises(ValueError):
+        sd.cbca(v, out, sup.clone(), 1, 14)      # a copy of the support tensor has lost its second plane
