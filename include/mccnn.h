@@ -151,6 +151,10 @@ int mccnn_bilateral(const float *image, const float *disp, int H, int W, int fh,
  * mccnn_l2norm_chw_to_hwc: tf.nn.l2_normalize over channels (model.py:64), x * rsqrt(max(sum x^2, 1e-12)), fused
  *   with the last layer's bias (bias may be NULL) and the layout change NCHW [C][H][W] -> NHWC [H][W][C]. */
 int mccnn_bias_act(float *x, const float *bias, int N, int C, long plane, int relu, mccnn_stream_t stream);
+/* First layer fused with the input padding (pf:20-25, model.py:51-53): images [N][H][W] -> out [N][C][H+2pad-2]
+ * [W+2pad-2] = relu(conv3x3_valid(zero_pad(image, pad), weights [C][1][3][3]) + bias [C]). */
+int mccnn_conv1_pad_bias_relu(const float *images, const float *weights, const float *bias, float *out, int N, int H,
+                              int W, int pad, int C, mccnn_stream_t stream);
 int mccnn_l2norm_chw_to_hwc(const float *chw, const float *bias, float *hwc, int C, int H, int W,
                             mccnn_stream_t stream);
 

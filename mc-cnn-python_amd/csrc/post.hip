@@ -259,6 +259,37 @@ __global__ __launch_bounds__(256) void bias_act_kernel(float *__restrict__ x, co
     }
 }
 
+// First layer of the stack (model.py:51-53: 1 -> C maps, 3x3 VALID, bias, ReLU) fused with the zero padding of the
+// input (process_functional.py:20-25): 9 multiply-adds per output do not deserve a library convolution plus three
+// elementwise launches.  Thread = one output pixel, looping over the C maps (weights / bias indexed uniformly: scalar
+// loads); every map's store is a coalesced row segment.
+__global__ __launch_bounds__(256) void conv1_pad_bias_relu_kernel(const float *__restrict__ img,
+                                                                  const float *__restrict__ w,
+                                                                  const float *__restrict__ bias,
+                                                                  float *__restrict__ out, int H, int W, int pad, int C,
+                                                                  int Ho, int Wo)
+{
+    const int xo = blockIdx.x * 256 + threadIdx.x;
+    const int yo = blockIdx.y, n = blockIdx.z;
+    if (xo >= Wo) return;
+    float v[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int y = yo + i - pad, x = xo + j - pad;
+            v[i * 3 + j] = (y >= 0 && y < H && x >= 0 && x < W) ? img[((size_t)n * H + y) * W + x] : 0.f;
+        }
+    float *o = out + ((size_t)n * C * Ho + yo) * Wo + xo;
+    for (int c = 0; c < C; ++c) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc += w[c * 9 + k] * v[k];
+        acc += bias[c];
+        o[(size_t)c * Ho * Wo] = fmaxf(acc, 0.f);
+    }
+}
+
 // tf.nn.l2_normalize(dim=-1) (model.py:64) of (conv output + last bias), NCHW in -> NHWC out: 64 pixels x C channels
 // per workgroup through a padded LDS tile: plane rows are read in 256-B runs and each pixel's C-vector is written as
 // one contiguous run.
@@ -373,6 +404,21 @@ extern "C" int mccnn_bias_act(float *x, const float *bias, int N, int C, long pl
     hipLaunchKernelGGL(bias_act_kernel, dim3(cdiv(plane, 1024), N * C), dim3(256), 0, (hipStream_t)stream, x, bias, C,
                        plane, relu);
     return check_launch("mccnn_bias_act");
+}
+
+extern "C" int mccnn_conv1_pad_bias_relu(const float *images, const float *weights, const float *bias, float *out,
+                                         int N, int H, int W, int pad, int C, mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(images && weights && bias && out, MCCNN_E_INVALID, "mccnn_conv1_pad_bias_relu: null pointer");
+    MCCNN_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && pad >= 0, MCCNN_E_INVALID,
+                  "mccnn_conv1_pad_bias_relu: bad size");
+    const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
+    MCCNN_REQUIRE(Ho > 0 && Wo > 0 && Ho <= 65535 && N <= 65535, MCCNN_E_UNSUPPORTED,
+                  "mccnn_conv1_pad_bias_relu: output %dx%d outside the grid", Wo, Ho);
+    hipLaunchKernelGGL(conv1_pad_bias_relu_kernel, dim3(cdiv(Wo, 256), Ho, N), dim3(256), 0, (hipStream_t)stream,
+                       images, weights, bias, out, H, W, pad, C, Ho, Wo);
+    return check_launch("mccnn_conv1_pad_bias_relu");
 }
 
 extern "C" int mccnn_l2norm_chw_to_hwc(const float *chw, const float *bias, float *hwc, int C, int H, int W,

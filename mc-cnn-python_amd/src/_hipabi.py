@@ -51,6 +51,7 @@ SIGNATURES = {
     "mccnn_median": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mccnn_bilateral": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _vp, _vp]),
     "mccnn_bias_act": (_i, [_vp, _vp, _i, _i, ctypes.c_long, _i, _vp]),
+    "mccnn_conv1_pad_bias_relu": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mccnn_l2norm_chw_to_hwc": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
 }
 

@@ -108,13 +108,21 @@ class NET(object):
             outs.append(x)
         return outs
 
-    def _convs_device(self, x):
-        """The whole-image stack on the GPU: MIOpen convolutions without bias, each followed by ONE in-place HIP pass
-        for bias + ReLU (mccnn_bias_act) instead of two elementwise launches; the last layer's bias is left to the
-        normalisation epilogue.  x: [B,1,h,w] -> [B,64,h-2n,w-2n] (contiguous)."""
+    def _convs_device(self, images, pad):
+        """The whole-image stack on the GPU.  images: [B,H,W] standardised views.  Layer 1 (1 -> 64 maps: 9
+        multiply-adds per output) runs fused with the zero padding, its bias and ReLU in one HIP launch
+        (mccnn_conv1_pad_bias_relu); layers 2..n are MIOpen convolutions without bias, each followed by ONE in-place
+        HIP pass for bias + ReLU (mccnn_bias_act); the last layer's bias is left to the normalisation epilogue.
+        Returns [B,64,H+2pad-2n,W+2pad-2n] (contiguous)."""
         import stereo_device
         nl = self.num_conv_layers
-        for k in range(nl):
+        if self.conv_kernel_size == 3 and nl >= 2:
+            x = stereo_device.conv1_pad_bias_relu(images.contiguous(), self.weights[0], self.biases[0], pad)
+            first = 1
+        else:
+            x = F.pad(images[:, None], (pad, pad, pad, pad))  # zero-pad ONCE; every conv is VALID
+            first = 0
+        for k in range(first, nl):
             x = F.conv2d(x, self.weights[k], None)
             if k < nl - 1:
                 x = stereo_device.bias_act_(x.contiguous(), self.biases[k], True)
@@ -147,8 +155,7 @@ class NET(object):
         pad = (self.input_patch_size - 1) // 2
         assert pad == self.num_conv_layers * (self.conv_kernel_size - 1) // 2, \
             "patch size must equal the receptive field so that features keep the image size"
-        x = F.pad(image_hw[None, None], (pad, pad, pad, pad))  # zero-pad ONCE; every conv is VALID
-        out = self._convs_device(x)[0]                         # [64,H,W] without the last bias
+        out = self._convs_device(image_hw[None], pad)[0]      # [64,H,W] without the last bias
         return stereo_device.l2norm_chw_to_hwc(out, self.biases[-1])
 
     def features_pair_hwc(self, left_hw, right_hw):
@@ -157,8 +164,7 @@ class NET(object):
         import stereo_device
         pad = (self.input_patch_size - 1) // 2
         assert pad == self.num_conv_layers * (self.conv_kernel_size - 1) // 2
-        x = F.pad(torch.stack((left_hw, right_hw))[:, None], (pad, pad, pad, pad))   # [2,1,H+2p,W+2p]
-        out = self._convs_device(x)                                                    # [2,64,H,W], last bias pending
+        out = self._convs_device(torch.stack((left_hw, right_hw)), pad)              # [2,64,H,W], last bias pending
         return (stereo_device.l2norm_chw_to_hwc(out[0], self.biases[-1]),
                 stereo_device.l2norm_chw_to_hwc(out[1], self.biases[-1]))
 

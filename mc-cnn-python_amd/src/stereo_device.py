@@ -62,6 +62,18 @@ def bias_act_(x, bias, relu):
     return x
 
 
+def conv1_pad_bias_relu(images, weight, bias, pad):
+    """images [N,H,W] -> [N,C,H+2pad-2,W+2pad-2]: zero padding + first 3x3 VALID conv (1 -> C maps) + bias + ReLU in one
+    launch (pf:20-25, model.py:51-53).  weight: torch layout [C,1,3,3]."""
+    N, H, W = images.shape
+    C = weight.shape[0]
+    assert tuple(weight.shape) == (C, 1, 3, 3) and images.is_contiguous() and weight.is_contiguous()
+    out = torch.empty((N, C, H + 2 * pad - 2, W + 2 * pad - 2), dtype=torch.float32, device=images.device)
+    hip.check(hip.load().mccnn_conv1_pad_bias_relu(hip.ptr(images), hip.ptr(weight), hip.ptr(bias), hip.ptr(out), N, H,
+                                                   W, int(pad), C, hip.stream()), "mccnn_conv1_pad_bias_relu")
+    return out
+
+
 def l2norm_chw_to_hwc(chw, bias=None):
     """[C,H,W] conv output (+ the last layer's bias) -> [H,W,C] unit feature vectors (model.py:64)."""
     C, H, W = chw.shape
