@@ -37,26 +37,38 @@ def parse():
                     help="bit-exact variants (NumPy-order cost volume, reference-order CBCA) instead of the fast ones")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="100x150", help="HxW window of the workload timed on the CPU oracle")
+    ap.add_argument("--cpu-cores", type=int, default=0,
+                    help="CPU-baseline worker processes (0 = half of the host threads, at most 16)")
     return ap.parse_args()
 
 
-def cpu_baseline(H, W, D, sample, layers):
-    """The oracle (a scalar C port of the reference's loops, oracle/mccnn_oracle.c) on a bounded window of the same
-    workload, one host thread.  Reported next to the GPU number; never on the measured path."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle as o
-    import synthetic
+def cpu_baseline(H, W, D, sample, cores, wpath):
+    """The oracle (a scalar C port of the reference's loops, oracle/mccnn_oracle.c) on bounded windows of the same
+    workload: `cores` worker processes (oracle/cpu_window.py), one window each, started together; the rate is all
+    their voxels over the slowest worker's time.  Reported next to the GPU number; never on the measured path."""
+    import subprocess
     sh, sw = [int(x) for x in sample.split("x")]
     sh, sw = min(sh, H), min(max(sw, D + 2), W)
-    L, R, _, _, _ = synthetic.make_pair(sh, sw, D, seed=1)
-    o.lib()
+    worker = os.path.join(ROOT, "oracle", "cpu_window.py")
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     t0 = time.perf_counter()
-    o.match_pair(L, R, D, layers)
-    dt = time.perf_counter() - t0
-    return {"value": round(sh * sw * D / dt / 1e6, 5), "unit": "Mdisparities/s", "cores": 1, "kind": "port",
-            "sample": "%dx%d window, D=%d (%.1f%% of the %dx%d workload), %.1f s on 1 of %d host threads; the "
-                      "reference's own interpreted loops measured 0.0068 Mdisp/s (BASELINE.md)"
-                      % (sw, sh, D, 100.0 * sh * sw / (H * W), W, H, dt, os.cpu_count() or 0)}
+    procs = [subprocess.Popen([sys.executable, worker, str(sh), str(sw), str(D), str(1 + i), wpath],
+                              stdout=subprocess.PIPE, env=env) for i in range(cores)]
+    secs = []
+    for p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("cpu_baseline worker failed")
+        secs.append(float(out.decode().strip().splitlines()[-1]))
+    wall = time.perf_counter() - t0
+    slowest = max(secs)
+    return {"value": round(cores * sh * sw * D / slowest / 1e6, 5), "unit": "Mdisparities/s", "cores": cores,
+            "kind": "port",
+            "sample": "%d workers x one %dx%d window, D=%d (%.1f%% of the %dx%d workload each), slowest %.1f s, "
+                      "fastest %.1f s (%.3f Mdisp/s per core), %.0f s wall on %d host threads; the reference's own "
+                      "interpreted loops measured 0.0068 Mdisp/s on one core (BASELINE.md)"
+                      % (cores, sw, sh, D, 100.0 * sh * sw / (H * W), W, H, slowest, min(secs),
+                         sh * sw * D / min(secs) / 1e6, wall, os.cpu_count() or 0)}
 
 
 def main():
@@ -180,7 +192,13 @@ def main():
         "stage_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
     }
     if not args.no_cpu_baseline and world == 1:
-        result["cpu_baseline"] = cpu_baseline(H, W, D, args.cpu_sample, layers)
+        cores = args.cpu_cores if args.cpu_cores > 0 else max(1, min(16, (os.cpu_count() or 2) // 2))
+        if not os.path.isfile(wpath):      # random-init run: hand the workers the same weights through a file
+            import tempfile
+            wpath = os.path.join(tempfile.mkdtemp(), "weights.npz")
+            np.savez(wpath, **{"conv%d/%s" % (k + 1, n): a for k, (w, b) in enumerate(layers)
+                               for n, a in (("weights", w), ("biases", b))})
+        result["cpu_baseline"] = cpu_baseline(H, W, D, args.cpu_sample, cores, wpath)
     else:
         result["cpu_baseline"] = None
     print(json.dumps(result))
