@@ -12,6 +12,7 @@
 //                       of HBM traffic, bound by the latency of a pipeline step (TA, VALU and LDS all ~50-60 % busy).
 //   cbca_iter_kernel    LDS-tiled; REFERENCE_ORDER variant walks the region in the reference's list order and is
 //                       bit-exact; its separable variant serves distances > 14.
+#include <math.h>
 #include "common.h"
 #ifndef PRIO_EMIT
 #define PRIO_EMIT 3
@@ -533,12 +534,30 @@ static int launch_cbca_pipe(const float *in, float *out, const Support *sup, int
     constexpr int OUTW = (CS_IN - ((R + 1) & ~1) - R) & ~1;
     MCCNN_REQUIRE(W >= 2, MCCNN_E_UNSUPPORTED, "mccnn_cbca_iter: W=%d < 2", W);
     const int nstrips = cdiv(W, OUTW);
-    // row chunks of ~128 rows: each chunk re-reads 2R halo rows, so taller is cheaper; more chunks = more workgroups
-    // Row chunks: every chunk re-stages 2R halo rows, so chunks are as tall as the launch allows while still giving
-    // the 256 CUs x 4 resident workgroups about two rounds of work (measured at 750x500x256: 4 chunks 0.40 ms,
-    // 2 chunks 0.37 ms, 1 chunk 0.35 ms); never shorter than 64 rows.
-    const int want = cdiv(2048, (long)nstrips * D);
-    const int nchunks = max(1, min(want, H / 64));
+    // Row chunks.  A strip of one plane can be cut into row chunks (each re-stages 2R halo rows).  The launch wants
+    // (a) tall chunks and (b) a workgroup count that fills whole rounds of the chip's 4-per-CU resident slots: with
+    // 1.0 < total/slots < 2.0 etc. the last round runs mostly empty (1242x375x192 in one chunk per strip: 2496
+    // workgroups = 2.44 rounds, 19 % of the slot-time idle).  Pick the chunk count with the best product of the two
+    // efficiencies; chunks are never shorter than 64 rows.  (750x500x256: 2048 workgroups = 2 full rounds in 1 chunk.)
+    static const int slots = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            cus = 256;
+        return 4 * (cus > 0 ? cus : 256);
+    }();
+    int nchunks = 1;
+    double best = -1.0;
+    for (int n = 1; n <= max(1, min(H / 64, 16)); ++n) {
+        const double rounds = (double)nstrips * D * n / slots;
+        const double fill = rounds / ceil(rounds);
+        const double rows_n = (double)H / n;
+        const double eff = fill * rows_n / (rows_n + 2 * R);
+        if (eff > best + 1e-9) {
+            best = eff;
+            nchunks = n;
+        }
+    }
     const int rows = cdiv(H, nchunks);
     const long total = (long)nstrips * nchunks * D;
     MCCNN_REQUIRE(total <= 0x7fffffffL && (long)H * W * 4 <= 0x7fffffffL, MCCNN_E_UNSUPPORTED,
