@@ -22,6 +22,12 @@
 #include "common.h"
 
 namespace mccnn {
+// Cache policy of the in-place scanline passes: every voxel is read once and written once per pass and the next pass
+// (another direction) comes back to it only after 1.5 GB of other traffic, so both the load and the store carry the
+// non-temporal hint (aux bit 1 = nt on gfx940+): 0.342 -> 0.319 ms horizontal, 0.312 -> 0.294 ms vertical.  The same
+// hint on the first pass's plane-major gathers (+28 %) or on the layout transposes (+8 % / no change) is a loss.
+constexpr int kNT = 2;
+
 
 // ---- flag planes ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sgm_flags_kernel(const float *__restrict__ img, int H, int W, int rh, int rw,
@@ -164,7 +170,7 @@ __global__ __launch_bounds__(64) void sgm_pass_kernel(const SgmParams P)
     };
     auto pos = [&](int t) { return (unsigned)(fwd ? t : nsteps - t); };
     auto load_vol = [&](int g, int t) {
-        const sgm_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs_vol, voff[g], pos(t) * vstride, 0);
+        const sgm_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs_vol, voff[g], pos(t) * vstride, kNT);
         return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
     };
 
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(64) void sgm_pass_kernel(const SgmParams P)
                 sgm_u32x4 ou;
                 ou.x = __float_as_uint(o.x); ou.y = __float_as_uint(o.y);
                 ou.z = __float_as_uint(o.z); ou.w = __float_as_uint(o.w);
-                __builtin_amdgcn_raw_buffer_store_b128(ou, rs_vol, voff[g], pos(t) * vstride, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(ou, rs_vol, voff[g], pos(t) * vstride, kNT);
                 lm = vmin(lm, vmin(vmin(o.x, o.y), vmin(o.z, o.w)));
             }
             issue(k, min(t + PF, nsteps));   // past the end: a harmless re-read of the last line (keeps the code branch-free)
