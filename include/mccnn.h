@@ -21,7 +21,7 @@
  *   volume    "DHW" [D][H][W]   - the reference's layout; cost volume, CBCA, WTA, sub-pixel use it
  *             "HWD" [H][W][Dp]  - pixel-major, Dp = mccnn_hwd_pitch(D); the SGM scanline kernels use it
  *   support   mccnn_support_bytes(H,W) bytes: plane 0 [H][W] uint32 words (four 5-bit cross-arm lengths + 12-bit
- *             region size, mccnn_support_t), plane 1 [H][W] uint64 "emit words" (1/size as float64 + vertical arms)
+ *             region size, mccnn_support_t), then two derived planes private to the streaming aggregation kernel
  *   maps      [H][W]        float32 disparity maps, int32 status / region counts
  */
 #ifndef MCCNN_H
@@ -66,13 +66,14 @@ int mccnn_cost_volume(const float *fl, const float *fr, int H, int W, int C, int
  *     bits 0-4 up | 5-9 down | 10-14 left | 15-19 right | 20-31 count        (arms <= 31, count <= 63*63)
  * hence L <= 32.  The reference's explicit coordinate list [H][W][(2L)^2][2] (padded with -1) is produced by
  * mccnn_cross_region_list for API compatibility only.
- * The support buffer holds a second, derived plane behind the first (16-byte aligned, at byte offset
- * roundup(H*W*4, 16)): [H][W] uint64 "emit words" = the bits of the float64 reciprocal 1/count rounded to 42
- * mantissa bits, with the freed low 10 bits carrying up (0-4) and down (5-9).  mccnn_cbca_iter's streaming kernel
- * reads it with one 16-byte load per two outputs.  Allocate mccnn_support_bytes(H, W) bytes; mccnn_cross_arms fills
- * both planes, and consumers that only want the arms / counts read the first H*W words. */
+ * The support buffer holds two derived planes behind the first (each 16-byte aligned), private to the streaming kernel
+ * of mccnn_cbca_iter and written for its LDS layout: [H][W] uint32 "hsum words" (LDS byte addresses of the two row-prefix
+ * entries whose difference is the pixel's horizontal-arm sum) and [H][W] uint64 "emit words" (the float64 reciprocal
+ * 1/count with the vertical arms in its 12 low mantissa bits; the 40 upper mantissa bits are chosen so that the word as
+ * stored is the float64 nearest to 1/count).  Allocate mccnn_support_bytes(H, W) bytes (16 per pixel + alignment);
+ * mccnn_cross_arms fills all planes, and consumers that only want the arms / counts read the first H*W words. */
 typedef uint32_t mccnn_support_t; /* plane 0 layout [H][W] */
-size_t mccnn_support_bytes(int H, int W); /* whole buffer: both planes (0 for non-positive sizes) */
+size_t mccnn_support_bytes(int H, int W); /* whole buffer: all planes (0 for non-positive sizes) */
 #define MCCNN_SUPPORT_UP(s) ((s) & 31u)
 #define MCCNN_SUPPORT_DOWN(s) (((s) >> 5) & 31u)
 #define MCCNN_SUPPORT_LEFT(s) (((s) >> 10) & 31u)
@@ -85,7 +86,8 @@ int mccnn_cross_region_list(const mccnn_support_t *support, int H, int W, int L,
 
 /* ---- a4  cost_volume_aggregation, ONE iteration on ONE volume (pf:149-163) -----------------------------------
  * out[d,p] = (sum_{q in U(p)} in[d,q]) / count[p];  in != out (ping-pong; the reference does not mutate either).
- * L is the distance threshold the support plane was built with (arms < L; supported: L <= 32).
+ * L is the distance threshold the support plane was built with (arms < L; supported: L <= 32); a plane that this
+ * library's mccnn_cross_arms built with a larger distance, or for another image size, is refused (MCCNN_E_INVALID).
  * order MCCNN_CBCA_SEPARABLE: horizontal-arm sums then vertical-arm sums evaluated through float64 prefix sums -
  * the correctly rounded region sum, within <= 1e-6 per iteration (O(1) costs) of the reference's sequential float32
  * sum, cost independent of the arm lengths; volumes must be finite (an inf/nan would poison its whole row).

@@ -3,21 +3,22 @@
 //
 // The reference materialises, per pixel, the coordinate list of its cross-shaped support region (int32
 // [H,W,784,2], 2.35 GB per image at 750x500) and then gathers through it.  Here a pixel carries
-// one packed 32-bit word (four 5-bit arm lengths + the 12-bit region size, mccnn_support_t) plus one derived 8-byte
-// "emit word" (reciprocal of the size + vertical arms); the region is regenerated from the arms.
+// one packed 32-bit word (four 5-bit arm lengths + the 12-bit region size, mccnn_support_t) plus two derived words
+// for the streaming kernel (ready-made LDS addresses of its horizontal lookups; reciprocal of the size + vertical arms);
+// the region is regenerated from the arms.
 //
 // Two aggregation kernels, same result set:
-//   cbca_pipe_kernel    (MCCNN_CBCA_SEPARABLE, default distance) - O(1) work per output via float64 prefix sums,
-//                       four wave-specialised stages stream a column strip of one disparity plane; 8 B/voxel/iteration
-//                       of HBM traffic, bound by the latency of a pipeline step (TA, VALU and LDS all ~50-60 % busy).
+//   cbca_stream_kernel  (MCCNN_CBCA_SEPARABLE, default distance) - O(1) work per output via float64 prefix sums,
+//                       wave-specialised stages stream 256-column strips of two disparity planes; 8 B/voxel/iteration
+//                       of HBM traffic.
 //   cbca_iter_kernel    LDS-tiled; REFERENCE_ORDER variant walks the region in the reference's list order and is
 //                       bit-exact; its separable variant serves distances > 14.
 #include <math.h>
+
+#include <mutex>
+#include <unordered_map>
+
 #include "common.h"
-#ifndef PRIO_EMIT
-#define PRIO_EMIT 3
-#define PRIO_HSUM 2
-#endif
 
 namespace mccnn {
 
@@ -73,37 +74,71 @@ __global__ __launch_bounds__(256) void cross_arms_kernel(const float *__restrict
     sup[(size_t)h * W + w] = (uint32_t)up | ((uint32_t)down << 5) | ((uint32_t)left << 10) | ((uint32_t)right << 15);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Geometry of the streaming aggregation kernel (cbca_stream_kernel below).  It is shared with cross_count_kernel
+// because the support planes carry, per pixel, ready-made LDS byte addresses for that kernel's layout: the pixel's
+// position inside its strip (and hence the lane and the LDS slot of every prefix-sum entry it needs) is a function of
+// its column alone, so the address arithmetic is done once per image instead of once per pixel per plane per iteration.
+namespace s4 {
+constexpr int R = 13;             // longest arm the kernel serves (distance threshold L <= 14)
+constexpr int CPL = 4;            // columns per lane
+constexpr int CS = 64 * CPL;      // staged columns per strip (one 16-byte load per lane per row)
+constexpr int HL = 16;            // staged columns left of the first output column (>= R + 1, multiple of CPL)
+constexpr int OUTW = 224;         // output columns per strip: HL + OUTW - 1 + R <= CS - 1; 7 x 128 bytes per row
+constexpr int B = 4;              // rows per pipeline batch
+constexpr int RING = 32;          // rows of the column-prefix ring (power of two: the wrap is a bit mask)
+constexpr int SUBB = 64 * 8;      // one column-phase sub-array: 64 lanes x 8 bytes
+constexpr int ROWB = CPL * SUBB;  // bytes of one staged row of float64 prefix sums (prow) / one ring row
+static_assert(HL >= R + 1 && HL % CPL == 0 && HL + OUTW + R <= CS && OUTW % CPL == 0, "strip geometry");
+static_assert(ROWB == 2048 && RING * ROWB == 65536, "the emit stage's address math assumes 2 KiB rows, 32 of them");
+// Column-phase layout of a row of 256 float64: entry i lives in sub-array i % 4 at slot i / 4, so the four values a
+// lane owns go out as four conflict-free 8-byte stores (lane stride 8 B) and gathers of neighbouring lanes that use
+// equal arms hit distinct banks.
+__host__ __device__ constexpr uint32_t elem(int i) { return (uint32_t)((i & 3) * SUBB + (i >> 2) * 8); }
+}  // namespace s4
+
+// Support buffer: plane 0 [H][W] uint32 (arms + size, documented in mccnn.h), then - each 16-byte aligned -
+//   plane 1 [H][W] uint32  "hsum words": LDS byte offsets (within one prow row) of the two prefix entries whose
+//                          difference is the pixel's horizontal-arm sum: bits 0-15 entry i+right, 16-31 entry i-left-1,
+//                          i = column % OUTW + HL;
+//   plane 2 [H][W] uint64  "emit words": the float64 reciprocal of the region size, whose 12 low mantissa bits carry
+//                          down (bits 7-11) and 31 - up (bits 2-6); the upper 40 mantissa bits are chosen so that the
+//                          word AS IT IS (fields included) is the float64 nearest to 1/n among the words with those low
+//                          bits - the kernel multiplies by it without masking (|rel. error| <= 2^-41).
+__host__ __device__ __forceinline__ size_t hsum_plane_offset(int H, int W) { return ((size_t)H * W * 4 + 15) & ~(size_t)15; }
+__host__ __device__ __forceinline__ size_t emit_plane_offset(int H, int W)
+{
+    return (hsum_plane_offset(H, W) + (size_t)H * W * 4 + 15) & ~(size_t)15;
+}
+
 // pf:640-653: region size = sum over the vertical arm of the horizontal arm sizes.  The size goes into the upper 12
 // bits of the same word whose lower 20 bits (the arms, written by the previous kernel and never changed here) the
 // neighbours are reading: relaxed atomics make that formally race-free, and any mix of old/new words is correct.
-//
-// The same kernel fills the second plane of the support buffer, the 8-byte "emit words" the streaming aggregation
-// kernel reads once per output: the float64 reciprocal 1/n rounded to 42 mantissa bits, whose 10 freed low bits
-// carry the vertical arms (0-4 up, 5-9 down).  One 16-byte load per lane then brings everything the emit stage needs
-// for two pixels, instead of a support word plus two table gathers (which cost ~55 cache-line lookups each).
-__host__ __device__ __forceinline__ size_t emit_plane_offset(int H, int W)
-{
-    return ((size_t)H * W * 4 + 15) & ~(size_t)15;
-}
-
+// The same kernel fills the derived planes of the support buffer (above).
 __global__ __launch_bounds__(256) void cross_count_kernel(Support *__restrict__ sup, int H, int W)
 {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     const int h = blockIdx.y;
     if (w >= W) return;
     auto ld = [&](size_t i) { return __hip_atomic_load(&sup[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    const uint32_t a = ld((size_t)h * W + w);
+    const size_t p = (size_t)h * W + w;
+    const uint32_t a = ld(p);
     uint32_t n = 0;
     for (int q = h - arm_up(a); q <= h + arm_down(a); ++q) {
         const uint32_t aq = ld((size_t)q * W + w);
         n += arm_left(aq) + arm_right(aq) + 1;
     }
-    __hip_atomic_fetch_or(&sup[(size_t)h * W + w], n << 20, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long bits = (unsigned long long)__double_as_longlong(1.0 / (double)n);
-    bits = (bits + 0x200ull) & ~0x3ffull;          // round to nearest at 42 mantissa bits
-    unsigned long long *emitw =
-        reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(sup) + emit_plane_offset(H, W));
-    emitw[(size_t)h * W + w] = bits | (a & 0x3ffu);
+    __hip_atomic_fetch_or(&sup[p], n << 20, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    char *base = reinterpret_cast<char *>(sup);
+    // arms beyond what the streaming kernel serves (L > 14 never reaches it) are clamped so the words stay in range
+    const int up = min(arm_up(a), s4::R), down = min(arm_down(a), s4::R);
+    const int left = min(arm_left(a), s4::R), right = min(arm_right(a), s4::R);
+    const int i = w % s4::OUTW + s4::HL;
+    reinterpret_cast<uint32_t *>(base + hsum_plane_offset(H, W))[p] = s4::elem(i + right) | (s4::elem(i - left - 1) << 16);
+    const unsigned long long rbits = (unsigned long long)__double_as_longlong(1.0 / (double)n);
+    const unsigned long long field = ((unsigned long long)down << 7) | ((unsigned long long)(31 - up) << 2);
+    reinterpret_cast<unsigned long long *>(base + emit_plane_offset(H, W))[p] =
+        (((rbits - field + 0x800ull) >> 12) << 12) | field;
 }
 
 // pf:637-655: explicit list, order (self, up.., down..) x (self, left.., right..), padded with (-1,-1)
@@ -145,6 +180,12 @@ __global__ __launch_bounds__(256) void cbca_iter_kernel(const float *__restrict_
     const int tid = threadIdx.x;
     const int w0 = blockIdx.x * CB_TW, h0 = blockIdx.y * CB_TH;
     const size_t plane = (size_t)H * W;
+    // arms are clamped to the staged halo: a support plane built with a larger distance than the caller states
+    // (mccnn_cbca_iter rejects that when it can tell) must not walk outside the tile
+    auto aL = [](uint32_t a) { return min(arm_left(a), R); };
+    auto aR = [](uint32_t a) { return min(arm_right(a), R); };
+    auto aU = [](uint32_t a) { return min(arm_up(a), R); };
+    auto aD = [](uint32_t a) { return min(arm_down(a), R); };
     const float *src = in + (size_t)blockIdx.z * plane;
     float *dst = out + (size_t)blockIdx.z * plane;
 
@@ -166,7 +207,7 @@ __global__ __launch_bounds__(256) void cbca_iter_kernel(const float *__restrict_
             if (hh >= 0 && hh < H && ww < W) {
                 const uint32_t a = sup[(size_t)hh * W + ww];
                 const float *row = &tin[r * IP + c + R];
-                for (int j = -arm_left(a); j <= arm_right(a); ++j) s += row[j];
+                for (int j = -aL(a); j <= aR(a); ++j) s += row[j];
             }
             ths[r * CB_TW + c] = s;
         }
@@ -180,7 +221,7 @@ __global__ __launch_bounds__(256) void cbca_iter_kernel(const float *__restrict_
                 const Support sp = sup[(size_t)hh * W + ww];
                 const float *col = &ths[(r + R) * CB_TW + c];
                 float s = 0.f;
-                for (int i = -arm_up(sp); i <= arm_down(sp); ++i) s += col[i * CB_TW];
+                for (int i = -aU(sp); i <= aD(sp); ++i) s += col[i * CB_TW];
                 dst[(size_t)hh * W + ww] = s / (float)sup_count(sp);  // pf:161
             }
         }
@@ -194,14 +235,14 @@ __global__ __launch_bounds__(256) void cbca_iter_kernel(const float *__restrict_
             if (hh < H && ww < W) {
                 const Support sp = sup[(size_t)hh * W + ww];
                 float s = 0.f;
-                const int nu = arm_up(sp), nv = 1 + nu + arm_down(sp);
+                const int nu = aU(sp), nv = 1 + nu + aD(sp);
                 for (int v = 0; v < nv; ++v) {
                     const int dq = v == 0 ? 0 : (v <= nu ? -v : v - nu);
                     const uint32_t aq = sup[(size_t)(hh + dq) * W + ww];
                     const float *row = &tin[(r + R + dq) * IP + c + R];
                     s += row[0];
-                    for (int z = 1; z <= arm_left(aq); ++z) s += row[-z];
-                    for (int z = 1; z <= arm_right(aq); ++z) s += row[z];
+                    for (int z = 1; z <= aL(aq); ++z) s += row[-z];
+                    for (int z = 1; z <= aR(aq); ++z) s += row[z];
                 }
                 dst[(size_t)hh * W + ww] = s / (float)sup_count(sp);
             }
@@ -221,40 +262,6 @@ static int launch_cbca(const float *in, float *out, const Support *sup, int D, i
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Streaming separable aggregation: O(1) work per output, independent of the arm lengths (MCCNN_CBCA_SEPARABLE).
-//
-// The per-pixel loops of cbca_iter_kernel cost (wave-maximum arm length) dependent LDS round trips per output.  Here
-// a strip of OUTW = 100 output columns of one disparity plane is streamed down its rows:
-//   row y arrives (2 floats per lane, 128 columns = 100 outputs + 14/13-column halos)
-//     -> float64 inclusive prefix sum P along the row (DPP scan across the 64 lanes)
-//     -> horizontal-arm sum of pixel (y,c) = P[c+right] - P[c-left-1]              (2 LDS reads)
-//     -> running float64 column prefix Q[y][c] += that, kept in an LDS ring
-//   row y-13 leaves: vertical-arm sum = Q[y'+down] - Q[y'-up-1], times 1/|U|, rounded once to float32.
-// float64 differences of prefix sums of float32 data carry ~1e-14 absolute error, so the result is the correctly
-// rounded region mean; it differs from the reference's sequential float32 sum only by that sum's own rounding
-// (same tolerance as any separable order).  Lanes never diverge.
-//
-// Wave specialisation.  A single wave per strip is bound by its own serial instruction chain (the float64 ring caps a
-// CU at ~5 such strips; measured 0.53-0.80 ms per iteration at 750x500x256).  So FOUR waves share one strip (one
-// ring) and each runs one stage of the row pipeline in lock step, one barrier per batch of B = 4 rows:
-//     iteration t:   waves 0,3  scan   batch t     (2 rows each)  -> prow[t & 1]
-//                    wave  1    hsum   batch t-1   prow lookups, column prefix -> ring rows
-//                    wave  2    emit   batch t-2   ring lookups, x 1/|U|, store
-// 16 waves per CU, and a strip advances at the pace of its slowest stage instead of the sum of all three (measured
-// alone at 750x500x256: scan 0.14 ms, hsum 0.16 ms, emit 0.21 ms; a fifth wave sharing the emit rows, one scan + two
-// emit waves, and 8-row batches were all slower).  Roles take s_setprio emit > hsum > scan: the emit wave is the one
-// that never waits at the barrier.
-//
-// Memory side.  The vector-memory (TA) pipe is the busiest unit (a wave instruction keeps it ~16 cycles + bytes/64),
-// so a row moves with four instructions: the 2 floats per lane (8 B), the packed support words of the staged row
-// (8 B: left/right arms of 2 pixels), the emit words of the leaving row (16 B: float64 reciprocal of the region size
-// with the vertical arms in its low mantissa bits, 2 pixels) and the 2-float store - all raw buffer ops: per-lane byte
-// offset + wave-uniform row offset, no address arithmetic.  Each descriptor spans one whole plane and every access
-// stays inside it by construction (the range check tests voffset + soffset against that span, per dword at the high
-// end; tools/probe/bufrange.hip): pairs entirely outside the image are clamped onto valid columns - no arm can reach
-// those elements, so any finite value cancels in the prefix differences - the one pair that can straddle the right
-// edge (odd W) is fetched one column early and swizzled, and stores of rows outside the chunk are dropped by a
-// per-lane offset beyond the span instead of a branch.
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ double dpp_f64(double x)
 {
@@ -263,315 +270,369 @@ __device__ __forceinline__ double dpp_f64(double x)
     return __hiloint2double(hi, lo);
 }
 
-constexpr int CS_IN = 128;  // staged columns per strip (2 per lane)
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <int R, int RING, bool ODDW>
-__global__ __launch_bounds__(256) void cbca_pipe_kernel(const float *__restrict__ in, float *__restrict__ out,
-                                                        const Support *__restrict__ sup, int H, int W, int rows,
-                                                        int nstrips, int nchunks, int total)
+// ---------------------------------------------------------------------------------------------------------------
+// cbca_stream_kernel: the separable aggregation (MCCNN_CBCA_SEPARABLE, L <= 14), O(1) work per output.
+//
+// A strip of 256 staged columns (224 outputs) of one disparity plane is streamed down its rows:
+//   row y arrives (4 floats per lane)
+//     -> float64 inclusive prefix sum P along the row (lane-local prefix + DPP scan across the 64 lanes)   [scan]
+//     -> horizontal-arm sum of pixel (y,c) = P[i+right] - P[i-left-1]; running float64 column prefix
+//        Q[y][c] += that, kept in a 32-row LDS ring                                                        [hsum]
+//   row y-13 leaves: vertical-arm sum = Q[y'+down] - Q[y'-up-1], times 1/|U|, rounded once to float32     [emit]
+// float64 differences of prefix sums of float32 data carry ~1e-14 absolute error, so the result is the correctly
+// rounded region mean (up to the 2^-41 of the stored reciprocal); it differs from the reference's sequential float32
+// sum only by that sum's own rounding.  Lanes never diverge and the cost does not depend on the arm lengths.
+//
+// What a row costs, and why it is laid out this way (MI355X, measured; DESIGN.md 4.2 has the numbers):
+//   * LDS addresses come ready-made in the support words (namespace s4): a horizontal lookup is one AND or one shift,
+//     a vertical lookup is v_lshl_add + v_and_or (the 32-row ring wraps by mask), the reciprocal is used as stored;
+//   * prow and the ring use the column-phase layout (s4::elem): stores and the ring gathers are conflict-free by
+//     construction, prow gathers are conflict-free wherever neighbouring lanes use equal arms;
+//   * 16-byte loads / stores per lane, halo columns 12.5 % of a strip, the 64-lane scan paid once per 256 columns.
+// Pipeline: waves are specialised by stage and run in lock step, one s_barrier per batch of B = 4 rows:
+//     iteration t:  scan  batch t    -> prow[t & 1]
+//                   hsum  batch t-1  -> ring rows 4(t-1) .. 4(t-1)+3
+//                   emit  batch t-2  :  "above" lookups Q[y+down] now; the "below" lookups Q[y-up-1] were fetched one
+//                                       iteration earlier (rows <= y-1 are long complete) - with that the 27-row
+//                                       window plus the rows being written fit the 32-row ring.
+// A workgroup runs PPW = 2 such pipelines (two planes of the same strip) behind the same barriers: the second one's
+// support words are the cache lines the first one just brought into L1 (TCP->L2 read requests -35 %).
+// Edges: nothing is clamped along a row.  Lanes whose columns fall outside the image read whatever the buffer range
+// check or the neighbouring row gives them (finite: volumes must be finite); no arm reaches those entries, so they
+// cancel in the prefix differences.  Rows past the bottom re-read the last row (never referenced).  Stores outside the
+// image / chunk are dropped by an out-of-range offset.
+#ifndef CBCA_NSCAN
+#define CBCA_NSCAN 1   // scan waves per pipeline (rows of a batch split between them)
+#define CBCA_NEMIT 2   // emit waves per pipeline (rows split)
+#endif
+#ifndef CBCA_NHS
+#define CBCA_NHS 1     // hsum waves per pipeline (each owns CPL / NHS of a lane's four columns)
+#endif
+#ifndef CBCA_PPW
+#define CBCA_PPW 2     // pipelines (planes) per workgroup
+#endif
+constexpr int NHS = CBCA_NHS;
+constexpr int PPW = CBCA_PPW;
+
+// One pipeline step: workgroup barrier, and nothing may be scheduled across it - without the scheduling barriers the
+// compiler hoists the register-only unpacking of all four unrolled batches above the first s_barrier, which turns
+// the s_waitcnt vmcnt(N) of the oldest batch into vmcnt(0) and serialises every iteration behind a fresh HBM load.
+__device__ __forceinline__ void pipe_sync()
 {
-    constexpr int RS = (R + 1) & ~1;           // staged halo on the left, even so that lanes own aligned column pairs
-    constexpr int OUTW = (CS_IN - RS - R) & ~1; // output columns per strip
-    constexpr int RP = (OUTW + 3) & ~1;        // ring pitch in doubles (even, > OUTW)
-    constexpr int B = 4;                       // rows per batch
-    constexpr int NPF = 4;                     // batches of loads each role keeps in flight
-    constexpr int PRP = CS_IN + 2;             // prow pitch: prow[k+1] = sum of staged elements 0..k, prow[0] = 0
-    // emit(t-2) reads logical rows [y0-2R-1, y0+B-1] of the ring while hsum(t-1) writes the next B rows: 2R+1+2B rows
-    // must not alias (a power-of-two ring would need 64 rows = 52 KB; 36 rows keep 4 workgroups per CU)
-    static_assert(RING >= 2 * R + 1 + 2 * B, "ring must hold the emit window plus the batch being written");
-    __shared__ double prow[2 * B * PRP];       // double-buffered by batch parity
-    __shared__ double ring[RING * RP];
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NSCAN, int NEMIT>
+__global__ __launch_bounds__(64 * PPW * (NSCAN + NHS + NEMIT)) void cbca_stream_kernel(
+    const float *__restrict__ in, float *__restrict__ out, const Support *__restrict__ sup, int D, int H, int W,
+    int rows, int nstrips, int nchunks, int total)
+{
+    using namespace s4;
+    constexpr int NPF = 4;                      // batches of loads every wave keeps in flight
+    constexpr int SR = B / NSCAN, ER = B / NEMIT;
+    constexpr int PROW_BYTES = 2 * B * ROWB;    // double-buffered by batch parity
+    constexpr int NW = NSCAN + NHS + NEMIT;     // waves of one pipeline
+    __shared__ double lds[PPW * (PROW_BYTES + RING * ROWB) / 8];   // 80 KiB per pipeline
     const int lane = threadIdx.x & 63;
-    // Role of this wave.  The dispatcher puts the four waves of a workgroup on the four SIMDs of a CU with a start
-    // SIMD that varies per workgroup, so with roles tied to the wave index a SIMD can end up hosting several emit
-    // waves (the longest stage) of the four resident workgroups.  Role = (SIMD id + wave slot) mod 4 gives every
-    // SIMD one wave of each role when resident workgroups occupy equal slots; if the four waves do not come out
-    // with four distinct roles (placement is not architecturally guaranteed), fall back to the wave index.
-    __shared__ int claim[4];
-    int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    {
-        uint32_t hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));   // [3:0] wave slot, [5:4] SIMD
-        const int pref = (int)(((hw >> 4) + hw) & 3u);
-        if (lane == 0) claim[wave] = pref;
-        __syncthreads();
-        const int seen = (1 << claim[0]) | (1 << claim[1]) | (1 << claim[2]) | (1 << claim[3]);
-        if (seen == 15) wave = pref;
-        wave = __builtin_amdgcn_readfirstlane(wave);
-    }
-    // XCD-aware order: consecutive work items (neighbouring strips of one plane share halo columns) stay on one
-    // XCD's L2; the dispatcher places block b on XCD b % 8 (speed only, any placement is correct)
+    const int wave_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // waves w and w + 4 of a workgroup share a SIMD: the second pipeline takes its roles in rotated order so that a
+    // pipeline's longest instruction stream (scan) is not paired with its twin
+    const int pipe = wave_wg / NW, wave = (wave_wg % NW + pipe * (NW / 2)) % NW;
+    char *const ldsb = reinterpret_cast<char *>(lds) + pipe * (PROW_BYTES + RING * ROWB);
     int id;
-    {
+    {   // XCD-aware order: neighbouring strips of one plane (shared halo columns, shared support rows) on one L2
         const int b = blockIdx.x, q = total >> 3, r = total & 7, x = b & 7;
         id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
     }
     const int strip = id % nstrips;
     const int chunk = (id / nstrips) % nchunks;
-    const int d = id / (nstrips * nchunks);
+    // an odd last plane is simply done by both pipelines (identical stores)
+    const int d = min((id / (nstrips * nchunks)) * PPW + pipe, D - 1);
     const int w0 = strip * OUTW, h0 = chunk * rows, h1 = min(h0 + rows, H);
     const int ys = max(h0 - R, 0), ye = min(h1 - 1 + R, H - 1);
-    const int ylast = h1 - 1 + R;
-    const int nb = (ylast - ys + B) / B;       // batches; batch k holds rows ys + k*B + (0..B-1)
+    const int nb = (h1 - 1 + R - ys + B) / B;   // batch k holds rows ys + k*B + (0..B-1)
     const size_t plane = (size_t)H * W;
-
-    const int x0 = w0 - RS + 2 * lane;         // image column of this lane's first staged element (even)
-    const int c0 = w0 + 2 * lane;              // this lane's first output column (even)
-    const bool oc0 = 2 * lane < OUTW && c0 < W, oc1 = 2 * lane + 1 < OUTW && c0 + 1 < W;
-    const int i0 = oc0 ? RS + 2 * lane : RS;   // staged index of output column c0 (idle lanes stay in bounds)
-    const bool rl = 2 * lane < RP;             // lane owns two ring columns
-    const bool vstr = ODDW && x0 == W - 1, sstr = ODDW && c0 == W - 1;
-    const int x0c = vstr ? W - 2 : min(max(x0, 0), W - 2);
-    const int c0c = sstr ? W - 2 : min(c0, W - 2);
-    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(in + (size_t)d * plane), 0, (int)(plane * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_dst =
-        __builtin_amdgcn_make_buffer_rsrc(out + (size_t)d * plane, 0, (int)(plane * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_sup =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<Support *>(sup), 0, (int)(plane * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_emit = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(sup)) + emit_plane_offset(H, W), 0, (int)(plane * 8),
-        0x00020000);
-    const int vb = 4 * x0c, sb = 4 * c0c, ob = 4 * c0;
     const int rowv = 4 * W;
+    const uint32_t lane8 = 8u * (uint32_t)lane;
+    const char *supb = reinterpret_cast<const char *>(sup);
 
-    if (threadIdx.x < 2 * B) prow[threadIdx.x * PRP] = 0.0;
-    if (wave == 1 && rl) {                     // Q of the row above the first staged row is zero
-        double *z = &ring[((ys - 1 + RING) % RING) * RP + lane];
-        z[0] = 0.0;
-        z[RP / 2] = 0.0;
-    }
+    // Iterations: T = NPF*n4 + 2, n4 = ceil(nb / NPF).  Every wave runs a two-iteration prologue and then n4 groups of
+    // NPF straight-line iterations (no exits, no guards: the compiler's s_waitcnt vmcnt counts stay exact, which is
+    // what keeps NPF batches of loads in flight).  Batches past nb are padding: their rows are clamped loads, their
+    // ring rows are never referenced and their stores are dropped.
+    const int n4 = (nb + NPF - 1) / NPF;
 
-    if (wave == 0 || wave == 3) {
-        // ---------------- scan role: rows b0, b0+1 of every batch ----------------
-        const int b0 = wave == 0 ? 0 : 2;
-        u32x2 vv[NPF][2];
+    if (wave < NSCAN) {
+        // ---------------- scan: rows b0 .. b0+SR-1 of batch t ----------------
+        const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(in + (size_t)d * plane), 0, (int)(plane * 4), 0x00020000);
+        const int b0 = wave * SR;
+        const int vb = 4 * max(w0 - HL + CPL * lane, 0);
+        u32x4 vv[NPF][SR];
         auto issue = [&](int slot, int k) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                vv[slot][j] = __builtin_amdgcn_raw_buffer_load_b64(rs_src, vb, min(ys + k * B + b0 + j, ye) * rowv, 0);
+            for (int j = 0; j < SR; ++j)
+                vv[slot][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, vb, min(ys + k * B + b0 + j, ye) * rowv, 0);
+        };
+        auto scan_batch = [&](int slot, int par, int t) {
+            double p0[SR], p1[SR], p2[SR], tt[SR], ex[SR];
+#pragma unroll
+            for (int j = 0; j < SR; ++j) {
+                p0[j] = (double)__uint_as_float(vv[slot][j].x);
+                p1[j] = p0[j] + (double)__uint_as_float(vv[slot][j].y);
+                p2[j] = p1[j] + (double)__uint_as_float(vv[slot][j].z);
+                tt[j] = p2[j] + (double)__uint_as_float(vv[slot][j].w);
+            }
+            // steps outermost so the rows' dependent chains interleave (a lone chain issues one VALU per ~5 cycles)
+#pragma unroll
+            for (int j = 0; j < SR; ++j) tt[j] += dpp_f64<0x111>(tt[j]);        // row_shr:1
+#pragma unroll
+            for (int j = 0; j < SR; ++j) tt[j] += dpp_f64<0x112>(tt[j]);        // row_shr:2
+#pragma unroll
+            for (int j = 0; j < SR; ++j) tt[j] += dpp_f64<0x114>(tt[j]);        // row_shr:4
+#pragma unroll
+            for (int j = 0; j < SR; ++j) tt[j] += dpp_f64<0x118>(tt[j]);        // row_shr:8
+#pragma unroll
+            for (int j = 0; j < SR; ++j) tt[j] += dpp_f64<0x142, 0xA>(tt[j]);   // row_bcast:15
+#pragma unroll
+            for (int j = 0; j < SR; ++j) tt[j] += dpp_f64<0x143, 0xC>(tt[j]);   // row_bcast:31
+#pragma unroll
+            for (int j = 0; j < SR; ++j) ex[j] = dpp_f64<0x138>(tt[j]);         // wave_shr:1 -> exclusive
+#pragma unroll
+            for (int j = 0; j < SR; ++j) {
+                char *pr = ldsb + (par * B + b0 + j) * ROWB + lane8;
+                *reinterpret_cast<double *>(pr + 0 * SUBB) = ex[j] + p0[j];
+                *reinterpret_cast<double *>(pr + 1 * SUBB) = ex[j] + p1[j];
+                *reinterpret_cast<double *>(pr + 2 * SUBB) = ex[j] + p2[j];
+                *reinterpret_cast<double *>(pr + 3 * SUBB) = tt[j];
+            }
+            issue(slot, t + NPF);
         };
 #pragma unroll
         for (int k = 0; k < NPF; ++k) issue(k, k);
-        for (int tb = 0; tb < nb + 2; tb += NPF) {
+        scan_batch(0, 0, 0);
+        pipe_sync();
+        scan_batch(1 % NPF, 1, 1);
+        pipe_sync();
+        for (int g = 0; g < n4; ++g) {
 #pragma unroll
             for (int u = 0; u < NPF; ++u) {
-                const int t = tb + u;
-                if (t >= nb + 2) break;
-                if (t < nb) {
-                    double a0[2], tt[2], ex[2];
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        a0[j] = (double)__uint_as_float(vstr ? vv[u][j].y : vv[u][j].x);
-                        tt[j] = a0[j] + (double)__uint_as_float(vv[u][j].y);
-                    }
-                    // steps outermost so the two rows' dependent chains interleave
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) tt[j] += dpp_f64<0x111>(tt[j]);        // row_shr:1
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) tt[j] += dpp_f64<0x112>(tt[j]);        // row_shr:2
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) tt[j] += dpp_f64<0x114>(tt[j]);        // row_shr:4
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) tt[j] += dpp_f64<0x118>(tt[j]);        // row_shr:8
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) tt[j] += dpp_f64<0x142, 0xA>(tt[j]);   // row_bcast:15
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) tt[j] += dpp_f64<0x143, 0xC>(tt[j]);   // row_bcast:31
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) ex[j] = dpp_f64<0x138>(tt[j]);         // wave_shr:1 -> exclusive
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        double2 pp;
-                        pp.x = ex[j] + a0[j];
-                        pp.y = tt[j];
-                        *reinterpret_cast<double2 *>(&prow[((t & 1) * B + b0 + j) * PRP + 1 + 2 * lane]) = pp;
-                    }
-                    issue(u, t + NPF);
-                }
-                __syncthreads();
+                scan_batch((u + 2) % NPF, u & 1, 2 + g * NPF + u);
+                pipe_sync();
             }
         }
-    } else if (wave == 1) {
-        // ---------------- hsum role: batch t-1 ----------------
-        __builtin_amdgcn_s_setprio(PRIO_HSUM);
-        double q0 = 0.0, q1 = 0.0;
-        u32x2 sy[NPF][B];
+    } else if (wave < NSCAN + NHS) {
+        // ---------------- hsum: batch t-1, columns j0 .. j0+CH-1 of every lane ----------------
+        const __amdgpu_buffer_rsrc_t rs_hs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char *>(supb) + hsum_plane_offset(H, W), 0, (int)(plane * 4), 0x00020000);
+        constexpr int CH = CPL / NHS;
+        const int j0 = (wave - NSCAN) * CH;
+        const int sb = 4 * (w0 + CPL * lane + j0);
+        double q[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) q[j] = 0.0;
+        uint32_t sy[NPF][B][CH];
         auto issue = [&](int slot, int k) {
 #pragma unroll
-            for (int b = 0; b < B; ++b)
-                sy[slot][b] = __builtin_amdgcn_raw_buffer_load_b64(rs_sup, sb, min(ys + k * B + b, ye) * rowv, 0);
+            for (int b = 0; b < B; ++b) {
+                const int so = min(ys + k * B + b, ye) * rowv;
+                if constexpr (CH == 4) {
+                    const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(rs_hs, sb, so, 0);
+                    sy[slot][b][0] = t4.x, sy[slot][b][1] = t4.y, sy[slot][b][2 % CH] = t4.z, sy[slot][b][3 % CH] = t4.w;
+                } else {
+                    const u32x2 t2 = __builtin_amdgcn_raw_buffer_load_b64(rs_hs, sb, so, 0);
+                    sy[slot][b][0] = t2.x, sy[slot][b][1] = t2.y;
+                }
+            }
+        };
+        auto hsum_batch = [&](int slot, int par, int k) {
+            double hs[B][CH];
+            {
+                double pa[B][CH], pb[B][CH];     // all prow reads in flight before the first use
+                const char *prb = ldsb + par * (B * ROWB);
+#pragma unroll
+                for (int b = 0; b < B; ++b)
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        const uint32_t wd = sy[slot][b][j];
+                        pa[b][j] = *reinterpret_cast<const double *>(prb + b * ROWB + (wd & 0xffffu));
+                        pb[b][j] = *reinterpret_cast<const double *>(prb + b * ROWB + (wd >> 16));
+                    }
+#pragma unroll
+                for (int b = 0; b < B; ++b)
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) hs[b][j] = pa[b][j] - pb[b][j];
+            }
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                // rows past the image bottom are staged from clamped loads and never referenced by an arm:
+                // they run through unconditionally into ring rows nobody reads
+                char *rr = ldsb + PROW_BYTES + ((k * B + b) & (RING - 1)) * ROWB + j0 * SUBB + lane8;
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    q[j] += hs[b][j];
+                    *reinterpret_cast<double *>(rr + j * SUBB) = q[j];
+                }
+            }
+            issue(slot, k + NPF);
         };
 #pragma unroll
         for (int k = 0; k < NPF; ++k) issue(k, k);
-        for (int tb = 0; tb < nb + 2; tb += NPF) {
+        {   // Q of the row above the first staged row (relative row -1 = ring slot 31) is zero
+            char *z = ldsb + PROW_BYTES + (RING - 1) * ROWB + j0 * SUBB + lane8;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) *reinterpret_cast<double *>(z + j * SUBB) = 0.0;
+        }
+        pipe_sync();
+        hsum_batch(0, 0, 0);
+        pipe_sync();
+        for (int g = 0; g < n4; ++g) {
 #pragma unroll
             for (int u = 0; u < NPF; ++u) {
-                const int t = tb + u;
-                if (t >= nb + 2) break;
-                const int k = t - 1;
-                const int slot = (u + NPF - 1) % NPF;
-                if (k >= 0 && k < nb) {
-                    double hs0[B], hs1[B];
-                    {
-                        double pa0[B], pb0[B], pa1[B], pb1[B];   // all 16 prow reads in flight before the first use
-                        const char *prb = reinterpret_cast<const char *>(prow) + (k & 1) * (B * PRP * 8);
-#pragma unroll
-                        for (int b = 0; b < B; ++b) {
-                            const uint32_t a = sstr ? sy[slot][b].y : sy[slot][b].x, c = sy[slot][b].y;
-                            const char *pr = prb + b * (PRP * 8) + 8 * i0;
-                            // sum over staged elements [i-left, i+right] = prow[i+right+1] - prow[i-left]
-                            pa0[b] = *reinterpret_cast<const double *>(pr + 8 * (arm_right(a) + 1));
-                            pb0[b] = *reinterpret_cast<const double *>(pr - 8 * arm_left(a));
-                            pa1[b] = *reinterpret_cast<const double *>(pr + 8 * (arm_right(c) + 2));
-                            pb1[b] = *reinterpret_cast<const double *>(pr + 8 - 8 * arm_left(c));
-                        }
-#pragma unroll
-                        for (int b = 0; b < B; ++b) {
-                            hs0[b] = pa0[b] - pb0[b];
-                            hs1[b] = pa1[b] - pb1[b];
-                        }
-                    }
-#pragma unroll
-                    for (int b = 0; b < B; ++b) {
-                        // rows past the image bottom are staged from clamped loads and never referenced by an arm,
-                        // so they run through unconditionally (straight-line code) into ring rows nobody reads
-                        const int y = ys + k * B + b;
-                        q0 += hs0[b];
-                        q1 += hs1[b];
-                        if (rl) {   // even column -> slot lane, odd column -> slot RP/2 + lane
-                            double *rr = &ring[(y % RING) * RP + lane];
-                            rr[0] = q0;
-                            rr[RP / 2] = q1;
-                        }
-                    }
-                    issue(slot, k + NPF);
-                }
-                __syncthreads();
+                hsum_batch((u + 1) % NPF, (u + 1) & 1, 1 + g * NPF + u);
+                pipe_sync();
             }
         }
     } else {
-        // ---------------- emit role: batch t-2 ----------------
-        __builtin_amdgcn_s_setprio(PRIO_EMIT);
-        constexpr int EB = B;      // (splitting the rows over two emit waves, 320-thread workgroups, measured slower)
-        constexpr int e0 = 0;
-        constexpr int kDrop = 0x7ffffff0;          // byte offset past every plane: the range check drops the store
-        const int obm = oc1 ? ob : kDrop;
-        u32x4 so[NPF][EB];                         // emit words of the two output pixels: {lo0, hi0, lo1, hi1}
+        // ---------------- emit: rows b0 .. b0+ER-1 of batch t-2 ----------------
+        const __amdgpu_buffer_rsrc_t rs_ew = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char *>(supb) + emit_plane_offset(H, W), 0, (int)(plane * 8), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_dst =
+            __builtin_amdgcn_make_buffer_rsrc(out + (size_t)d * plane, 0, (int)(plane * 4), 0x00020000);
+        const int b0 = (wave - NSCAN - NHS) * ER;
+        const int c0 = w0 + CPL * lane;
+        constexpr int kDrop = 0x7ffffff0;        // byte offset past every plane: the range check drops the store
+        const int nval = lane < OUTW / CPL ? min(max(W - c0, 0), CPL) : 0;   // valid output columns of this lane
+        const int ob = 4 * c0;
+        const int obf = nval == CPL ? ob : kDrop;
+        const bool ragged = __builtin_amdgcn_readfirstlane((W & (CPL - 1)) != 0 && w0 + OUTW > W);
+        const int eb = 8 * c0;
+        const char *ringb = ldsb + PROW_BYTES;
+        u32x4 ew[NPF][ER][2];                    // emit words of 4 pixels: {lo0, hi0, lo1, hi1}, {lo2, hi2, lo3, hi3}
+        double qb[ER][CPL];                      // "below" lookups of the batch emitted in the next iteration
         auto issue = [&](int slot, int k) {
 #pragma unroll
-            for (int b = 0; b < EB; ++b)
-                so[slot][b] = __builtin_amdgcn_raw_buffer_load_b128(
-                    rs_emit, 2 * sb, min(max(ys + k * B + e0 + b - R, h0), h1 - 1) * (2 * rowv), 0);
+            for (int b = 0; b < ER; ++b) {
+                const int so = min(max(ys + k * B + b0 + b - R, h0), h1 - 1) * (2 * rowv);
+                ew[slot][b][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_ew, eb, so, 0);
+                ew[slot][b][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_ew, eb + 16, so, 0);
+            }
+        };
+        // ring lookups of batch k: sh = 4 selects the "down" field ((y + down) mod 32), sh = 9 the "31 - up" field
+        auto lookups = [&](int slot, int k, int sh, double (&dst)[ER][CPL]) {
+#pragma unroll
+            for (int b = 0; b < ER; ++b) {
+                uint32_t yms = (uint32_t)(k * B + b0 + b - R) << 11;   // bits >= 16 fall to the mask
+                asm volatile("" : "+s"(yms));    // one SGPR per row (else the constant is added per lane)
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    const uint32_t lo = ew[slot][b][j >> 1][(j & 1) * 2];
+                    const uint32_t ad = (((lo << sh) + yms) & 0xF800u) | lane8;
+                    dst[b][j] = *reinterpret_cast<const double *>(ringb + ad + j * SUBB);
+                }
+            }
+        };
+        auto emit_batch = [&](int sa, int sn, int ka) {
+            double qa[ER][CPL], qn[ER][CPL];
+            lookups(sa, ka, 4, qa);
+            lookups(sn, ka + 1, 9, qn);
+#pragma unroll
+            for (int b = 0; b < ER; ++b) {
+                const int yo = ys + ka * B + b0 + b - R;
+                const bool valid = yo >= h0 && yo < h1;      // wave-uniform
+                const int so = min(max(yo, h0), h1 - 1) * rowv;
+                u32x4 o;
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    const uint32_t lo = ew[sa][b][j >> 1][(j & 1) * 2], hi = ew[sa][b][j >> 1][(j & 1) * 2 + 1];
+                    const double rn = __hiloint2double((int)hi, (int)lo);
+                    o[j] = __float_as_uint((float)((qa[b][j] - qb[b][j]) * rn));
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs_dst, valid ? obf : kDrop, so, 0);
+                if (ragged && valid && nval > 0 && nval < CPL) {   // the one lane that straddles the right edge
+                    if (nval >= 2) {
+                        u32x2 o2 = {o.x, o.y};
+                        __builtin_amdgcn_raw_buffer_store_b64(o2, rs_dst, ob, so, 0);
+                        if (nval == 3) __builtin_amdgcn_raw_buffer_store_b32(o.z, rs_dst, ob + 8, so, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b32(o.x, rs_dst, ob, so, 0);
+                    }
+                }
+            }
+            issue(sa, ka + NPF);
+#pragma unroll
+            for (int b = 0; b < ER; ++b)
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) qb[b][j] = qn[b][j];
         };
 #pragma unroll
         for (int k = 0; k < NPF; ++k) issue(k, k);
-        for (int tb = 0; tb < nb + 2; tb += NPF) {
+        pipe_sync();
+        lookups(0, 0, 9, qb);                    // iteration 1: "below" lookups of batch 0 (rows < its first row)
+        pipe_sync();
+        for (int g = 0; g < n4; ++g) {
 #pragma unroll
             for (int u = 0; u < NPF; ++u) {
-                const int t = tb + u;
-                if (t >= nb + 2) break;
-                const int k = t - 2;
-                const int slot = (u + NPF - 2) % NPF;
-                if (k >= 0 && k < nb) {
-                    // Straight-line for the whole batch: all ring reads are issued before the first is consumed
-                    // (one LDS round trip per batch, not per row).  Rows outside the chunk compute on clamped
-                    // indices and their store is dropped by an out-of-range buffer offset.
-                    double qa0[EB], qb0[EB], qa1[EB], qb1[EB];
-                    const char *ringb = reinterpret_cast<const char *>(ring);
-                    const unsigned colb = 8u * (unsigned)lane;           // byte offset of this lane's even column in a ring row
-#pragma unroll
-                    for (int b = 0; b < EB; ++b) {
-                        const int yoc = min(max(ys + k * B + e0 + b - R, h0), h1 - 1);
-                        const uint32_t a = sstr ? so[slot][b].z : so[slot][b].x, c = so[slot][b].z;
-                        const int ym = yoc % RING;   // wave-uniform; per-lane wrap by unsigned min
-                        auto below = [&](int up) {
-                            const int i = ym - up - 1;
-                            return __umul24(min((unsigned)i, (unsigned)(i + RING)), RP * 8u);
-                        };
-                        auto above = [&](int dn) {
-                            const int i = ym + dn;
-                            return __umul24(min((unsigned)i, (unsigned)(i - RING)), RP * 8u);
-                        };
-                        qa0[b] = *reinterpret_cast<const double *>(ringb + above(arm_down(a)) + colb);
-                        qb0[b] = *reinterpret_cast<const double *>(ringb + below(arm_up(a)) + colb);
-                        qa1[b] = *reinterpret_cast<const double *>(ringb + above(arm_down(c)) + colb + 4 * RP);
-                        qb1[b] = *reinterpret_cast<const double *>(ringb + below(arm_up(c)) + colb + 4 * RP);
-                    }
-#pragma unroll
-                    for (int b = 0; b < EB; ++b) {
-                        const int yo = ys + k * B + e0 + b - R;
-                        const bool valid = yo >= h0 && yo < h1;      // wave-uniform
-                        const int yoc = min(max(yo, h0), h1 - 1);
-                        u32x2 o;
-                        const u32x4 e = so[slot][b];
-                        const double rn0 = __hiloint2double((int)(sstr ? e.w : e.y), (int)((sstr ? e.z : e.x) & ~0x3ffu));
-                        const double rn1 = __hiloint2double((int)e.w, (int)(e.z & ~0x3ffu));
-                        o.x = __float_as_uint((float)((qa0[b] - qb0[b]) * rn0));
-                        o.y = __float_as_uint((float)((qa1[b] - qb1[b]) * rn1));
-                        if (!ODDW) {
-                            __builtin_amdgcn_raw_buffer_store_b64(o, rs_dst, valid ? obm : kDrop, yoc * rowv, 0);
-                        } else if (valid) {
-                            if (oc1)
-                                __builtin_amdgcn_raw_buffer_store_b64(o, rs_dst, ob, yoc * rowv, 0);
-                            else if (oc0)
-                                __builtin_amdgcn_raw_buffer_store_b32(o.x, rs_dst, ob, yoc * rowv, 0);
-                        }
-                    }
-                    issue(slot, k + NPF);
-                }
-                __syncthreads();
+                emit_batch(u, (u + 1) % NPF, g * NPF + u);
+                pipe_sync();
             }
         }
     }
 }
 
-template <int R, int RING>
-static int launch_cbca_pipe(const float *in, float *out, const Support *sup, int D, int H, int W, hipStream_t s)
+template <int NSCAN, int NEMIT>
+static int launch_cbca_stream(const float *in, float *out, const Support *sup, int D, int H, int W, hipStream_t s)
 {
-    constexpr int OUTW = (CS_IN - ((R + 1) & ~1) - R) & ~1;
-    MCCNN_REQUIRE(W >= 2, MCCNN_E_UNSUPPORTED, "mccnn_cbca_iter: W=%d < 2", W);
-    const int nstrips = cdiv(W, OUTW);
-    // Row chunks.  A strip of one plane can be cut into row chunks (each re-stages 2R halo rows).  The launch wants
-    // (a) tall chunks and (b) a workgroup count that fills whole rounds of the chip's 4-per-CU resident slots: with
-    // 1.0 < total/slots < 2.0 etc. the last round runs mostly empty (1242x375x192 in one chunk per strip: 2496
-    // workgroups = 2.44 rounds, 19 % of the slot-time idle).  Pick the chunk count with the best product of the two
-    // efficiencies; chunks are never shorter than 64 rows.  (750x500x256: 2048 workgroups = 2 full rounds in 1 chunk.)
+    const int nstrips = cdiv(W, s4::OUTW);
+    // Row chunks: a strip of one plane can be cut into row chunks (each re-stages 2R halo rows).  The launch wants
+    // tall chunks and a workgroup count that fills whole rounds of the chip's 2-per-CU resident slots; pick the chunk
+    // count with the best product of the two efficiencies, chunks never shorter than 64 rows.
     static const int slots = [] {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             cus = 256;
-        return 4 * (cus > 0 ? cus : 256);
+        return (2 / PPW) * (cus > 0 ? cus : 256);
     }();
+    const int DG = cdiv(D, PPW);                 // plane groups
     int nchunks = 1;
     double best = -1.0;
     for (int n = 1; n <= max(1, min(H / 64, 16)); ++n) {
-        const double rounds = (double)nstrips * D * n / slots;
+        const double rounds = (double)nstrips * DG * n / slots;
         const double fill = rounds / ceil(rounds);
         const double rows_n = (double)H / n;
-        const double eff = fill * rows_n / (rows_n + 2 * R);
+        const double eff = fill * rows_n / (rows_n + 2 * s4::R);
         if (eff > best + 1e-9) {
             best = eff;
             nchunks = n;
         }
     }
     const int rows = cdiv(H, nchunks);
-    const long total = (long)nstrips * nchunks * D;
-    MCCNN_REQUIRE(total <= 0x7fffffffL && (long)H * W * 4 <= 0x7fffffffL, MCCNN_E_UNSUPPORTED,
+    const long total = (long)nstrips * nchunks * DG;
+    MCCNN_REQUIRE(total <= 0x7fffffffL && (long)H * W * 8 <= 0x7fffffffL, MCCNN_E_UNSUPPORTED,
                   "mccnn_cbca_iter: image %dx%d / volume too large for 32-bit buffer offsets", W, H);
-    if (W & 1)
-        hipLaunchKernelGGL((cbca_pipe_kernel<R, RING, true>), dim3((unsigned)total), dim3(256), 0, s, in, out, sup, H,
-                           W, rows, nstrips, nchunks, (int)total);
-    else
-        hipLaunchKernelGGL((cbca_pipe_kernel<R, RING, false>), dim3((unsigned)total), dim3(256), 0, s, in, out, sup, H,
-                           W, rows, nstrips, nchunks, (int)total);
-    return check_launch("mccnn_cbca_iter(pipe)");
+    hipLaunchKernelGGL((cbca_stream_kernel<NSCAN, NEMIT>), dim3((unsigned)total),
+                       dim3(64 * PPW * (NSCAN + NHS + NEMIT)), 0, s, in, out, sup, D, H, W, rows, nstrips, nchunks,
+                       (int)total);
+    return check_launch("mccnn_cbca_iter(stream)");
 }
 
 }  // namespace mccnn
+
+// Host-side record of what mccnn_cross_arms last wrote where (pointer -> H, W, L), so that mccnn_cbca_iter can refuse a
+// support plane built for another image size or with longer arms than the distance it is told (which selects the
+// kernel and its halo).  Pointers it has never seen (e.g. a device-side copy) pass: the kernels are memory-safe for
+// any arms (clamped above / baked within range), only the sums would be those of the clamped region.
+namespace {
+struct SupportInfo { int H, W, L; };
+std::mutex g_support_mu;
+std::unordered_map<const void *, SupportInfo> g_support;
+}  // namespace
 
 extern "C" size_t mccnn_support_bytes(int H, int W)
 {
@@ -593,7 +654,13 @@ extern "C" int mccnn_cross_arms(const float *image, int H, int W, float tau, int
     int rc = check_launch("mccnn_cross_arms");
     if (rc) return rc;
     hipLaunchKernelGGL(cross_count_kernel, grid, block, 0, s, support, H, W);
-    return check_launch("mccnn_cross_arms(count)");
+    rc = check_launch("mccnn_cross_arms(count)");
+    if (rc == 0) {
+        std::lock_guard<std::mutex> lock(g_support_mu);
+        if (g_support.size() > 4096) g_support.clear();   // bounded: stale entries only cost a missed check
+        g_support[support] = SupportInfo{H, W, L};
+    }
+    return rc;
 }
 
 extern "C" int mccnn_cross_region_list(const mccnn_support_t *support, int H, int W, int L, int32_t *region,
@@ -618,8 +685,20 @@ extern "C" int mccnn_cbca_iter(const float *in, float *out, const mccnn_support_
     MCCNN_REQUIRE(D <= 65535, MCCNN_E_UNSUPPORTED, "mccnn_cbca_iter: D=%d exceeds grid.z", D);
     MCCNN_REQUIRE(order == MCCNN_CBCA_SEPARABLE || order == MCCNN_CBCA_REFERENCE_ORDER, MCCNN_E_INVALID,
                   "mccnn_cbca_iter: unknown order %d", order);
+    {
+        std::lock_guard<std::mutex> lock(g_support_mu);
+        const auto it = g_support.find(support);
+        if (it != g_support.end()) {
+            MCCNN_REQUIRE(it->second.H == H && it->second.W == W, MCCNN_E_INVALID,
+                          "mccnn_cbca_iter: support plane was built for a %dx%d image, volume is %dx%d", it->second.W,
+                          it->second.H, W, H);
+            MCCNN_REQUIRE(it->second.L <= L, MCCNN_E_INVALID,
+                          "mccnn_cbca_iter: support plane was built with distance %d, called with L=%d", it->second.L, L);
+        }
+    }
     hipStream_t s = (hipStream_t)stream;
-    if (order == MCCNN_CBCA_SEPARABLE && L <= 14) return launch_cbca_pipe<13, 36>(in, out, support, D, H, W, s);
+    if (order == MCCNN_CBCA_SEPARABLE && L <= 14)
+        return launch_cbca_stream<CBCA_NSCAN, CBCA_NEMIT>(in, out, support, D, H, W, s);
     if (L <= 14) return launch_cbca<13, 32>(in, out, support, D, H, W, order, s);
     if (L <= 32) return launch_cbca<31, 16>(in, out, support, D, H, W, order, s);
     MCCNN_REQUIRE(false, MCCNN_E_UNSUPPORTED, "mccnn_cbca_iter: L=%d > 32 not built", L);

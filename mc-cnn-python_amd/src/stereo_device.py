@@ -100,7 +100,7 @@ def cost_volume(fl, fr, ndisp, mode=hip.MCCNN_CV_EXACT, out=None):
 def cross_arms(image, intensity_threshold, distance_threshold):
     """image [H,W] -> support plane, int32 [H,W]: one packed word per pixel (mccnn_support_t: bits 0-4 up, 5-9 down,
     10-14 left, 15-19 right, 20-31 region size).  support_arms()/support_count() decode it.  The returned tensor is
-    a view of the first plane of a mccnn_support_bytes(H, W) buffer; the derived second plane (the 8-byte words the
+    a view of the first plane of a mccnn_support_bytes(H, W) buffer; the derived planes (the words the
     streaming CBCA kernel reads) lives behind it in the same storage and travels with the view."""
     H, W = image.shape
     nbytes = int(hip.load().mccnn_support_bytes(H, W))
@@ -140,7 +140,7 @@ def cbca(vol, tmp, support, iterations, distance_threshold, order=hip.MCCNN_CBCA
     lib = hip.load()
     have = support.untyped_storage().nbytes() - support.storage_offset() * support.element_size()
     if tuple(support.shape) != (H, W) or not support.is_contiguous() or have < lib.mccnn_support_bytes(H, W):
-        raise ValueError("cbca: `support` must be the tensor cross_arms() returned (a copy drops its second plane)")
+        raise ValueError("cbca: `support` must be the tensor cross_arms() returned (a copy drops its derived planes)")
     src, dst = vol, tmp
     timer = timer or _NO_TIMER
     for _ in range(int(iterations)):
