@@ -36,23 +36,34 @@ def parse():
     ap.add_argument("--exact", action="store_true",
                     help="bit-exact variants (NumPy-order cost volume, reference-order CBCA) instead of the fast ones")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", default="100x150", help="HxW window of the workload timed on the CPU oracle")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch the ~75 kernels of a pair one by one instead of replaying the captured hipGraph")
+    ap.add_argument("--cpu-sample", default="cfg1",
+                    help="what every CPU-baseline worker runs: a BASELINE config name (one whole pair, default cfg1) "
+                         "or an HxW window of the benchmarked workload")
     ap.add_argument("--cpu-cores", type=int, default=0,
                     help="CPU-baseline worker processes (0 = half of the host threads, at most 16)")
     return ap.parse_args()
 
 
 def cpu_baseline(H, W, D, sample, cores, wpath):
-    """The oracle (a scalar C port of the reference's loops, oracle/mccnn_oracle.c) on bounded windows of the same
-    workload: `cores` worker processes (oracle/cpu_window.py), one window each, started together; the rate is all
-    their voxels over the slowest worker's time.  Reported next to the GPU number; never on the measured path."""
+    """The oracle (a scalar C port of the reference's loops, oracle/mccnn_oracle.c) timed on the host: `cores` worker
+    processes (oracle/cpu_window.py) started together, each pushing ONE whole stereo pair of a BASELINE config
+    (default cfg1, 256x256 D=64: the reference's own CPU-runnable case) - or one window of the benchmarked workload
+    - through the complete timed region; the rate is all their voxels over the slowest worker's time.  Reported
+    next to the GPU number; never on the measured path."""
     import subprocess
-    sh, sw = [int(x) for x in sample.split("x")]
-    sh, sw = min(sh, H), min(max(sw, D + 2), W)
+    if sample in CONFIGS:
+        sh, sw, sd_ = CONFIGS[sample]
+        what = "one whole %s pair (%dx%d, D=%d)" % (sample, sw, sh, sd_)
+    else:
+        sh, sw = [int(x) for x in sample.split("x")]
+        sh, sw, sd_ = min(sh, H), min(max(sw, D + 2), W), D
+        what = "one %dx%d window, D=%d (%.1f%% of the %dx%d workload)" % (sw, sh, sd_, 100.0 * sh * sw / (H * W), W, H)
     worker = os.path.join(ROOT, "oracle", "cpu_window.py")
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     t0 = time.perf_counter()
-    procs = [subprocess.Popen([sys.executable, worker, str(sh), str(sw), str(D), str(1 + i), wpath],
+    procs = [subprocess.Popen([sys.executable, worker, str(sh), str(sw), str(sd_), str(1 + i), wpath],
                               stdout=subprocess.PIPE, env=env) for i in range(cores)]
     secs = []
     for p in procs:
@@ -62,13 +73,46 @@ def cpu_baseline(H, W, D, sample, cores, wpath):
         secs.append(float(out.decode().strip().splitlines()[-1]))
     wall = time.perf_counter() - t0
     slowest = max(secs)
-    return {"value": round(cores * sh * sw * D / slowest / 1e6, 5), "unit": "Mdisparities/s", "cores": cores,
+    return {"value": round(cores * sh * sw * sd_ / slowest / 1e6, 5), "unit": "Mdisparities/s", "cores": cores,
             "kind": "port",
-            "sample": "%d workers x one %dx%d window, D=%d (%.1f%% of the %dx%d workload each), slowest %.1f s, "
-                      "fastest %.1f s (%.3f Mdisp/s per core), %.0f s wall on %d host threads; the reference's own "
-                      "interpreted loops measured 0.0068 Mdisp/s on one core (BASELINE.md)"
-                      % (cores, sw, sh, D, 100.0 * sh * sw / (H * W), W, H, slowest, min(secs),
-                         sh * sw * D / min(secs) / 1e6, wall, os.cpu_count() or 0)}
+            "sample": "%d workers x %s each, whole timed region incl. the conv stack; slowest %.1f s, fastest %.1f s "
+                      "(%.3f Mdisp/s per core), %.0f s wall on %d host threads; the reference's own interpreted "
+                      "loops measured 0.0068 Mdisp/s on one core (BASELINE.md)"
+                      % (cores, what, slowest, min(secs), sh * sw * sd_ / min(secs) / 1e6, wall, os.cpu_count() or 0)}
+
+
+def run_host_io(matcher, host_left, host_right, D, use_graph):
+    """One pair the way match.py:129-179 times it: standardised host images in, host disparity map out."""
+    dl = host_left.cuda(non_blocking=True)
+    dr = host_right.cuda(non_blocking=True)
+    out = matcher.match_graph(dl, dr, D) if use_graph else matcher.match(dl, dr, D)
+    return out.cpu()
+
+
+def traffic_table(config):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json): they cannot be
+    counted live.  An entry is used only when it was taken on this workload AND the kernel source it names still has
+    the hash recorded with it - otherwise the kernel has changed since it was profiled and traffic is null."""
+    import hashlib
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.isfile(tpath):
+        return {}
+    with open(tpath) as f:
+        tj = json.load(f)
+    if tj.get("workload") != config:
+        return {}
+    out = {}
+    for k, v in tj.items():
+        if not isinstance(v, dict) or "traffic_bytes" not in v:
+            continue
+        src = os.path.join(ROOT, v.get("source", ""))
+        if not os.path.isfile(src):
+            continue
+        with open(src, "rb") as f:
+            if hashlib.sha256(f.read()).hexdigest()[:16] != v.get("source_sha256_16"):
+                continue
+        out[k] = {"bytes": int(v["traffic_bytes"]), "from": v.get("profile")}
+    return out
 
 
 def main():
@@ -98,10 +142,13 @@ def main():
     shared = os.environ.get("MCCNN_BENCH_SHARED_GPU") == "1"
     device_index = local_rank % torch.cuda.device_count() if shared else local_rank
     torch.cuda.set_device(device_index)
+    # MCCNN_BENCH_FORCE_DIST=1 (tests): join a process group even at world size 1, so that the RCCL initialisation,
+    # barrier and all_gather of the multi-GPU path run on a one-GPU box
+    force = os.environ.get("MCCNN_BENCH_FORCE_DIST") == "1"
     if shared:
-        mgpu.init("gloo")
+        mgpu.init("gloo", always=force)
     else:
-        mgpu.init("nccl", torch.device("cuda", device_index))   # RCCL; only the barrier + timing all_gather use it
+        mgpu.init("nccl", torch.device("cuda", device_index), always=force)   # RCCL: barrier + timing all_gather only
 
     H, W, D = CONFIGS[args.config]
     wpath = os.path.join(ROOT, "tests", "golden", "mccnn_fast_weights.npz")
@@ -119,14 +166,16 @@ def main():
         net, cv_mode=hip.MCCNN_CV_EXACT if args.exact else hip.MCCNN_CV_MFMA,
         cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER if args.exact else hip.MCCNN_CBCA_SEPARABLE)
 
-    for _ in range(args.warmup):
-        matcher.match(dl, dr, D)
+    use_graph = not args.no_graph
+    run = (lambda: matcher.match_graph(dl, dr, D)) if use_graph else (lambda: matcher.match(dl, dr, D))
+    for _ in range(max(args.warmup, 1 if use_graph else 0)):      # the first graph call captures
+        run()
     torch.cuda.synchronize()
     mgpu.barrier()
-    timer = sd.StageTimer(True)
+    # headline loop: nothing but K pairs between the two synchronisation points (no per-stage events in here)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = matcher.match(dl, dr, D, timer=timer)
+        out = run()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     mgpu.barrier()
@@ -136,10 +185,30 @@ def main():
         mgpu.finalize()
         return
 
+    # side measurements on rank 0, outside the reported number
+    nside = max(2, min(args.steps, 5))
+    timer = sd.StageTimer(True)                  # per-launch HIP events, launches issued one by one
+    matcher.match(dl, dr, D)
+    torch.cuda.synchronize()
+    for _ in range(nside):
+        matcher.match(dl, dr, D, timer=timer)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()                     # launches one by one, no events
+    for _ in range(nside):
+        matcher.match(dl, dr, D)
+    torch.cuda.synchronize()
+    eager_ms = (time.perf_counter() - t1) / nside * 1e3
+    hl, hr = torch.from_numpy(L[:, :, 0].copy()).pin_memory(), torch.from_numpy(R[:, :, 0].copy()).pin_memory()
+    t2 = time.perf_counter()                     # match.py's own region: host images in, host map out
+    for _ in range(nside):
+        res = run_host_io(matcher, hl, hr, D, use_graph)
+    host_io_ms = (time.perf_counter() - t2) / nside * 1e3
+    del res
+
     voxels = H * W * D
     value = world * voxels * args.steps / elapsed_max / 1e6
     stages = {k: float(np.mean(v)) for k, v in timer.summary_ms().items()}          # mean ms per launch / stage
-    counts = {k: len(v) // args.steps for k, v in timer.summary_ms().items()}
+    counts = {k: len(v) // nside for k, v in timer.summary_ms().items()}
     per_step = {k: stages[k] * counts[k] for k in stages}                            # ms per step
     vol_bytes = 4.0 * voxels
     # algorithmic bytes per launch (SURVEY 8d / DESIGN.md): one read + one write of every voxel the launch owns
@@ -148,21 +217,15 @@ def main():
         "sgm_pass": 2 * 2 * vol_bytes,    # one direction on BOTH volumes (one launch advances left + right)
         "sgm_first_pass": 2 * 2 * vol_bytes,
     }
-    # HBM-side bytes per launch cannot be counted live (PMC needs rocprofv3): they come from the committed PMC passes of
-    # the same kernels on the same workload (profiles/pmc_traffic.json, see profiles/r01_pmc_summary.md), else null
-    traffic = {}
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.isfile(tpath) and not args.exact:
-        with open(tpath) as f:
-            tj = json.load(f)
-        if tj.get("workload") == args.config:
-            traffic = {k: int(v["traffic_bytes"]) for k, v in tj.items() if isinstance(v, dict)}
+    traffic = {} if args.exact else traffic_table(args.config)
     rooflines = {}
     for k, b in algo.items():
         if k in stages:
             ach = b / (stages[k] * 1e-3) / 1e9
             rooflines[k] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(k),
+                            "frac": round(ach / HBM_PEAK_GBS, 4),
+                            "traffic": traffic[k]["bytes"] if k in traffic else None,
+                            "traffic_from": traffic[k]["from"] if k in traffic else None,
                             "launches_per_step": counts[k], "avg_launch_ms": round(stages[k], 4),
                             "algorithmic_bytes_per_launch": int(b)}
     dominant = max(rooflines, key=lambda k: per_step[k]) if rooflines else None
@@ -171,12 +234,13 @@ def main():
                     per_step.get("dhw_to_hwd", 0.0) + per_step.get("hwd_to_dhw", 0.0))
     sgm_kern_ms = per_step.get("sgm_pass", 0.0) + per_step.get("sgm_first_pass", 0.0)
     result = {
-        "metric": "Mdisparities/s (HxWxD / s) end-to-end match.py timed region",
+        "metric": "Mdisparities/s (HxWxD / s) end-to-end match.py timed region, images resident in HBM",
         "value": round(value, 2), "unit": "Mdisparities/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %dx%d synthetic stereo pair, D=%d, one pair per GPU" % (args.config, W, H, D),
                    "variant": "exact" if args.exact else "fast (MFMA cost volume, separable CBCA)",
+                   "launch": "one hipGraph replay per pair" if use_graph else "kernel by kernel",
                    "weights": "converted reference checkpoint" if os.path.isfile(wpath) else "random init"},
         "roofline": dict(rooflines[dominant], kernel=dominant) if dominant else None,
         "rooflines": rooflines,
@@ -190,6 +254,13 @@ def main():
                         "frac_of_hbm_peak": round(4 * 2 * 2 * vol_bytes / (sgm_kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                         if sgm_kern_ms else None},
         "stage_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
+        # the same pair measured other ways (rank 0, 5 pairs each, outside `value`): launches issued one by one;
+        # and match.py's own timed region, host images in / host map out over PCIe (pinned buffers)
+        "ms_per_step_kernel_by_kernel": round(eager_ms, 3),
+        "ms_per_step_host_in_host_out": round(host_io_ms, 3),
+        "sum_of_stage_ms": round(sum(per_step.values()), 3),
+        "process_group": (torch.distributed.get_backend() + " x%d" % torch.distributed.get_world_size())
+        if torch.distributed.is_initialized() else None,
     }
     if not args.no_cpu_baseline and world == 1:
         cores = args.cpu_cores if args.cpu_cores > 0 else max(1, min(16, (os.cpu_count() or 2) // 2))

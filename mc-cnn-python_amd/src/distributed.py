@@ -18,11 +18,12 @@ def env_rank_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init(backend=None, device=None):
-    """Joins the process group when WORLD_SIZE > 1 (rendezvous on 127.0.0.1 unless MASTER_ADDR is set).
-    Returns (rank, local_rank, world)."""
+def init(backend=None, device=None, always=False):
+    """Joins the process group when WORLD_SIZE > 1 - or, with `always`, also as a group of one, which runs the same
+    RCCL initialisation, barrier and all_gather a multi-GPU job does (rendezvous on 127.0.0.1 unless MASTER_ADDR is
+    set).  Returns (rank, local_rank, world)."""
     rank, local_rank, world = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or always) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:

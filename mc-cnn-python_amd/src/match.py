@@ -8,8 +8,10 @@ im1.png + calib.txt beside it, standardises both views, runs the timed region (f
     <save_dir>/submit_<tag>/<rel>/disp0MCCNN.pfm, timeMCCNN.txt   and   <save_dir>/submit_<tag>_imgs/<rel>/disp0MCCNN.pgm
 exactly where the reference does (match.py:99-110, 182-184).
 
-Additions (all optional): --exact selects the bit-exact variants of the two stages that have a faster, tolerance-
-bounded form (cost volume on NumPy's summation order instead of MFMA; CBCA in the reference's list order).
+By default every stage after the conv features is bit-identical to the reference's NumPy code on the same inputs.
+Addition: --fast selects the tolerance-bounded variants of the two stages that have one (cost volume on the matrix
+cores instead of NumPy's summation order, <= 2e-6; CBCA through float64 prefix sums instead of the reference's list
+order, <= 1e-6 per iteration) - about 10x faster; near-ties in the WTA can then resolve differently.
 Multi-GPU: launch one process per GPU with different -g / -s / -e, as the reference intends (match.py:17, 26-28),
 or use `torchrun --nproc-per-node N match.py ...`: rank r then takes the pairs i = r (mod N) of the window.
 """
@@ -20,37 +22,45 @@ from datetime import datetime
 
 import numpy as np
 
+# Flag names, types and defaults are the reference's command line (match.py:15-43) - that is the drop-in contract;
+# the help texts are this project's.
 parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter,
-                                 description="stereo matching based on trained model and post-processing")
-parser.add_argument("-g", "--gpu", type=str, default="0", help="gpu id to use, \
-                    multiple ids should be separated by commons(e.g. 0,1,2,3)")
-parser.add_argument("-ps", "--patch_size", type=int, default=11, help="length for height/width of square patch")
-parser.add_argument("--list_file", type=str, required=True, help="path to file containing left image list")
-parser.add_argument("--resume", type=str, default=None, help="path to checkpoint to resume from. \
-                    (TensorFlow bundle prefix as in the reference, or an .npz of conv<k>/weights|biases)")
-parser.add_argument("--data_dir", type=str, required=True, help="path to root dir to data.")
-parser.add_argument("--save_dir", type=str, required=True, help="path to root dir to save results")
-parser.add_argument("-t", "--tag", type=str, required=True, help="tag used to indicate one run")
-parser.add_argument("-s", "--start", type=int, required=True, help="index of first image to do matching,\
-                                                                    this is used for parallel matching of different images")
-parser.add_argument("-e", "--end", type=int, required=True, help="index of last image to do matching")
+                                 description="MC-CNN stereo matching of a list of Middlebury-style pairs on one MI355X")
+parser.add_argument("-g", "--gpu", type=str, default="0",
+                    help="index of the GPU this process uses (ignored under torchrun: one rank per GPU)")
+parser.add_argument("-ps", "--patch_size", type=int, default=11,
+                    help="receptive field of the matching network (11 = five 3x3 layers)")
+parser.add_argument("--list_file", type=str, required=True, help="text file with one left-image path (.../im0.png) per line")
+parser.add_argument("--resume", type=str, default=None,
+                    help="network weights: TensorFlow checkpoint prefix as written by the reference's train.py, or an "
+                         ".npz of conv<k>/weights and conv<k>/biases")
+parser.add_argument("--data_dir", type=str, required=True, help="root of the input tree (prefix of the listed paths)")
+parser.add_argument("--save_dir", type=str, required=True, help="root under which submit_<tag>/ and submit_<tag>_imgs/ are written")
+parser.add_argument("-t", "--tag", type=str, required=True, help="name of this run (part of the output directory names)")
+parser.add_argument("-s", "--start", type=int, required=True,
+                    help="first list index to match (inclusive) - split a list over several processes with -s/-e")
+parser.add_argument("-e", "--end", type=int, required=True, help="last list index to match (inclusive)")
 
-# hyperparemeters, use suggested value from origin paper as default (match.py:31-43; the three CBCA counts are declared
-# float there but only work as the ints they default to - they are coerced with int() here)
-parser.add_argument("--cbca_intensity", type=float, default=0.02, help="intensity threshold for cross-based cost aggregation")
-parser.add_argument("--cbca_distance", type=float, default=14, help="distance threshold for cross-based cost aggregation")
-parser.add_argument("--cbca_num_iterations1", type=float, default=2, help="cross-based cost aggregation rounds before SGM")
-parser.add_argument("--cbca_num_iterations2", type=float, default=16, help="cross-based cost aggregation rounds after SGM")
-parser.add_argument("--sgm_P1", type=float, default=2.3, help="hyperparemeter used in semi-global matching")
-parser.add_argument("--sgm_P2", type=float, default=55.9, help="hyperparemeter used in semi-global matching")
-parser.add_argument("--sgm_Q1", type=float, default=4, help="hyperparemeter used in semi-global matching")
-parser.add_argument("--sgm_Q2", type=float, default=8, help="hyperparemeter used in semi-global matching")
-parser.add_argument("--sgm_D", type=float, default=0.08, help="hyperparemeter used in semi-global matching")
-parser.add_argument("--sgm_V", type=float, default=1.5, help="hyperparemeter used in semi-global matching")
-parser.add_argument("--blur_sigma", type=float, default=6, help="hyperparemeter used in bilateral filter")
-parser.add_argument("--blur_threshold", type=float, default=2, help="hyperparemeter used in bilateral filter")
-parser.add_argument("--exact", action="store_true", help="bit-exact stage variants (NumPy-order cost volume, "
-                    "reference-order CBCA) instead of the fast tolerance-bounded ones")
+# hyper-parameters, defaults from the MC-CNN paper as in match.py:31-43 (the three CBCA values are declared float there
+# but only work as the ints they default to - they are coerced with int() below)
+parser.add_argument("--cbca_intensity", type=float, default=0.02, help="CBCA: largest |I(q) - I(p)| along a support arm")
+parser.add_argument("--cbca_distance", type=float, default=14, help="CBCA: arm length limit (arms are shorter than this)")
+parser.add_argument("--cbca_num_iterations1", type=float, default=2, help="CBCA iterations before SGM")
+parser.add_argument("--cbca_num_iterations2", type=float, default=16, help="CBCA iterations after SGM")
+parser.add_argument("--sgm_P1", type=float, default=2.3, help="SGM: penalty for a disparity change of one")
+parser.add_argument("--sgm_P2", type=float, default=55.9, help="SGM: penalty for larger disparity changes")
+parser.add_argument("--sgm_Q1", type=float, default=4, help="SGM: penalties divided by this where one view has an intensity edge")
+parser.add_argument("--sgm_Q2", type=float, default=8, help="SGM: penalties divided by this where both views have one")
+parser.add_argument("--sgm_D", type=float, default=0.08, help="SGM: intensity difference that counts as an edge")
+parser.add_argument("--sgm_V", type=float, default=1.5, help="SGM: P1 is divided by this in the vertical directions")
+parser.add_argument("--blur_sigma", type=float, default=6, help="bilateral filter: spatial sigma")
+parser.add_argument("--blur_threshold", type=float, default=2, help="bilateral filter: intensity gate")
+# additions of this implementation
+parser.add_argument("--fast", action="store_true",
+                    help="use the tolerance-bounded fast variants of two stages (cost volume on the matrix cores, "
+                         "<= 2e-6; CBCA through float64 prefix sums, <= 1e-6 per iteration) - about 10x faster.  "
+                         "Without it every stage after the conv features is bit-identical to the reference's NumPy code")
+parser.add_argument("--exact", action="store_true", help="(default; kept for compatibility) the bit-exact variants")
 
 # different file names
 left_image_suffix = "im0.png"
@@ -74,76 +84,72 @@ def hyper_parameters(args):
 
 def main(argv=None):
     args = parser.parse_args(argv)
+    if args.fast and args.exact:
+        parser.error("--fast and --exact exclude each other")
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1:
-        # the reference pins the process to the requested card through the environment (match.py:59)
-        os.environ.setdefault("HIP_VISIBLE_DEVICES", args.gpu)
+        # the reference pins the process to the requested card through the environment (match.py:59); ROCm reads
+        # HIP_VISIBLE_DEVICES, torch also honours CUDA_VISIBLE_DEVICES - both are set to the same value
+        os.environ["HIP_VISIBLE_DEVICES"] = args.gpu
         os.environ["CUDA_VISIBLE_DEVICES"] = args.gpu
 
     import torch
     import _hipabi as hip
     import stereo_device as sd
     import util
+    from distributed import shard_indices
     from model import NET
 
     hip.require_device()
-    torch.cuda.set_device(local_rank if world > 1 else 0)
+    # one rank per GPU under torchrun; MCCNN_SHARED_GPU=1 (tests) lets several ranks share the visible GPUs
+    shared = os.environ.get("MCCNN_SHARED_GPU") == "1"
+    torch.cuda.set_device((local_rank % torch.cuda.device_count() if shared else local_rank) if world > 1 else 0)
 
-    patch_height = args.patch_size
-    save_dir = args.save_dir
-    data_dir = args.data_dir
-    save_res_dir = os.path.join(save_dir, "submit_{}".format(args.tag))
-    save_img_dir = os.path.join(save_dir, "submit_{}_imgs".format(args.tag))
-    util.recurMk(os.path.abspath(save_res_dir))
-    util.recurMk(os.path.abspath(save_img_dir))
+    result_root = os.path.join(args.save_dir, "submit_{}".format(args.tag))        # match.py:69-72
+    image_root = os.path.join(args.save_dir, "submit_{}_imgs".format(args.tag))
+    util.recurMk(os.path.abspath(result_root))
+    util.recurMk(os.path.abspath(image_root))
 
-    with open(args.list_file, "r") as i:
-        img_paths = i.readlines()
+    with open(args.list_file, "r") as f:
+        left_paths = [line.strip() for line in f.readlines()]
 
-    net = NET(None, input_patch_size=patch_height, num_conv_layers=(patch_height - 1) // 2, batch_size=1,
+    net = NET(None, input_patch_size=args.patch_size, num_conv_layers=(args.patch_size - 1) // 2, batch_size=1,
               device="cuda")
     net.restore(args.resume)  # loaded once and kept resident (the reference re-restores per pair)
     matcher = sd.StereoMatcher(
         net, hyper_parameters(args),
-        cv_mode=hip.MCCNN_CV_EXACT if args.exact else hip.MCCNN_CV_MFMA,
-        cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER if args.exact else hip.MCCNN_CBCA_SEPARABLE)
+        cv_mode=hip.MCCNN_CV_MFMA if args.fast else hip.MCCNN_CV_EXACT,
+        cbca_order=hip.MCCNN_CBCA_SEPARABLE if args.fast else hip.MCCNN_CBCA_REFERENCE_ORDER)
 
-    from distributed import shard_indices
-    for index in shard_indices(args.start, args.end, len(img_paths), rank, world):
-        left_path = img_paths[index].strip()
-        print("index: {}".format(index))
+    for index in shard_indices(args.start, args.end, len(left_paths), rank, world):
+        left_path = left_paths[index]
         right_path = left_path.replace(left_image_suffix, right_image_suffix)
         calib_path = left_path.replace(left_image_suffix, calib_suffix)
-
-        res_dir = left_path.replace(data_dir, save_res_dir)
-        img_dir = left_path.replace(data_dir, save_img_dir)
-        res_dir = res_dir[:res_dir.rfind(left_image_suffix) - 1]
-        img_dir = img_dir[:img_dir.rfind(left_image_suffix) - 1]
+        # outputs mirror the input tree under the two roots (match.py:99-110): <root>/<dir of im0.png relative to data_dir>
+        pair_dir = os.path.dirname(left_path)
+        res_dir = pair_dir.replace(args.data_dir, result_root)
+        img_dir = pair_dir.replace(args.data_dir, image_root)
         util.recurMk(os.path.abspath(res_dir))
         util.recurMk(os.path.abspath(img_dir))
-
         out_path = os.path.join(res_dir, out_file)
         out_time_path = os.path.join(res_dir, out_time_file)
         out_img_path = os.path.join(img_dir, out_img_file)
 
         height, width, ndisp = util.parseCalib(calib_path)
-        print("left_image: {}\nright_image: {}".format(left_path, right_path))
-        print("height: {}, width: {}, ndisp: {}".format(height, width, ndisp))
-        print("out_path: {}\nout_time_path: {}\nout_img_path: {}".format(out_path, out_time_path, out_img_path))
+        print("[{}] pair {}: {} | {}  ({}x{}, ndisp {})".format(rank, index, left_path, right_path, width, height, ndisp))
 
-        # reading images (match.py:118-125)
-        left_image = util.read_gray(left_path).astype(np.float32)
-        right_image = util.read_gray(right_path).astype(np.float32)
-        left_image = (left_image - np.mean(left_image, axis=(0, 1))) / np.std(left_image, axis=(0, 1))
-        right_image = (right_image - np.mean(right_image, axis=(0, 1))) / np.std(right_image, axis=(0, 1))
-        left_image = np.expand_dims(left_image, axis=2)
-        right_image = np.expand_dims(right_image, axis=2)
+        # decode + standardise (match.py:118-125): population std, no /255
+        views = []
+        for path in (left_path, right_path):
+            g = util.read_gray(path).astype(np.float32)
+            g = (g - np.mean(g, axis=(0, 1))) / np.std(g, axis=(0, 1))
+            views.append(np.expand_dims(g, axis=2))
+        left_image, right_image = views
         assert left_image.shape == (height, width, 1)
         assert right_image.shape == (height, width, 1)
-        print("{}: images read".format(datetime.now()))
 
         # timed region (match.py:129-179): host arrays in, host array out, device-synchronised
         stTime = time.time()
@@ -152,12 +158,11 @@ def main(argv=None):
         disparity = matcher.match(dev_l, dev_r, ndisp)
         left_disparity_map = disparity.cpu().numpy()
         endTime = time.time()
-        print("{}: refined".format(datetime.now()))
 
         util.saveDisparity(left_disparity_map, out_img_path)
         util.writePfm(left_disparity_map, out_path)
         util.saveTimeFile(endTime - stTime, out_time_path)
-        print("{}: saved".format(datetime.now()))
+        print("[{}] {}: {:.3f} s -> {}".format(rank, datetime.now(), endTime - stTime, out_path))
 
 
 if __name__ == "__main__":

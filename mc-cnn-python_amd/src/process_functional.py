@@ -9,9 +9,10 @@ HBM, processed, and copied back - use stereo_device.StereoMatcher to keep a whol
 
 There is no CPU fallback: without a HIP device or without the built library every function raises.
 
-Options the reference does not have (module attributes, defaults chosen for speed):
-    COST_VOLUME_MODE  "exact" (NumPy summation order, bit-exact) | "mfma" (matrix cores, <= 2e-6 abs)
-    CBCA_ORDER        "separable" (fast, <= 1e-6 abs per iteration) | "reference" (flat list order, bit-exact)
+Options the reference does not have (module attributes; the DEFAULTS are the bit-exact variants, so that a drop-in
+user gets the reference's numbers - the fast ones are opt-in and only tolerance-bounded):
+    COST_VOLUME_MODE  "exact" (NumPy summation order, bit-exact, default) | "mfma" (matrix cores, <= 2e-6 abs)
+    CBCA_ORDER        "reference" (flat list order, bit-exact, default) | "separable" (fast, <= 1e-6 abs per iteration)
 """
 import numpy as np
 import torch
@@ -21,7 +22,7 @@ import stereo_device as sd
 from model import NET
 
 COST_VOLUME_MODE = "exact"
-CBCA_ORDER = "separable"
+CBCA_ORDER = "reference"
 
 _CV_MODES = {"exact": hip.MCCNN_CV_EXACT, "mfma": hip.MCCNN_CV_MFMA}
 _CBCA_ORDERS = {"separable": hip.MCCNN_CBCA_SEPARABLE, "reference": hip.MCCNN_CBCA_REFERENCE_ORDER}

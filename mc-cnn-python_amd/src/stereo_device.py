@@ -97,15 +97,20 @@ def cost_volume(fl, fr, ndisp, mode=hip.MCCNN_CV_EXACT, out=None):
 
 
 # ---- a3 ----------------------------------------------------------------------------------------------------------
-def cross_arms(image, intensity_threshold, distance_threshold):
+def support_buffer(H, W, device):
+    """An empty support plane (see cross_arms): the [H,W] view of a mccnn_support_bytes(H, W) allocation."""
+    nbytes = int(hip.load().mccnn_support_bytes(H, W))
+    buf = torch.empty(((nbytes + 3) // 4,), dtype=torch.int32, device=device)
+    return buf[:H * W].view(H, W)
+
+
+def cross_arms(image, intensity_threshold, distance_threshold, out=None):
     """image [H,W] -> support plane, int32 [H,W]: one packed word per pixel (mccnn_support_t: bits 0-4 up, 5-9 down,
     10-14 left, 15-19 right, 20-31 region size).  support_arms()/support_count() decode it.  The returned tensor is
-    a view of the first plane of a mccnn_support_bytes(H, W) buffer; the derived planes (the words the
-    streaming CBCA kernel reads) lives behind it in the same storage and travels with the view."""
+    a view of the first plane of a mccnn_support_bytes(H, W) buffer; the derived planes (the words the streaming
+    CBCA kernel reads) live behind it in the same storage and travel with the view.  `out`: a support_buffer()."""
     H, W = image.shape
-    nbytes = int(hip.load().mccnn_support_bytes(H, W))
-    buf = torch.empty(((nbytes + 3) // 4,), dtype=torch.int32, device=image.device)
-    support = buf[:H * W].view(H, W)
+    support = out if out is not None else support_buffer(H, W, image.device)
     hip.check(hip.load().mccnn_cross_arms(hip.ptr(image), H, W, _f32(intensity_threshold), int(distance_threshold),
                                           hip.ptr(support), hip.stream()), "mccnn_cross_arms")
     return support
@@ -244,40 +249,40 @@ def sgm_average_from_dhw(image_left, image_right, vols_dhw, vols_hwd, sides, D, 
 
 
 # ---- a7 .. a11 -----------------------------------------------------------------------------------------------------
-def wta(vol):
+def wta(vol, out=None):
     D, H, W = vol.shape
-    disp = torch.empty((H, W), dtype=torch.float32, device=vol.device)
+    disp = out if out is not None else torch.empty((H, W), dtype=torch.float32, device=vol.device)
     hip.check(hip.load().mccnn_wta(hip.ptr(vol), D, H, W, hip.ptr(disp), hip.stream()), "mccnn_wta")
     return disp
 
 
-def lr_status(dl, dr, ndisp):
+def lr_status(dl, dr, ndisp, out=None):
     H, W = dl.shape
-    st = torch.empty((H, W), dtype=torch.int32, device=dl.device)
+    st = out if out is not None else torch.empty((H, W), dtype=torch.int32, device=dl.device)
     hip.check(hip.load().mccnn_lr_status(hip.ptr(dl), hip.ptr(dr), H, W, int(ndisp), hip.ptr(st), hip.stream()),
               "mccnn_lr_status")
     return st
 
 
-def interpolate(dl, status):
+def interpolate(dl, status, out=None):
     H, W = dl.shape
-    out = torch.empty_like(dl)
+    out = out if out is not None else torch.empty_like(dl)
     hip.check(hip.load().mccnn_interpolate(hip.ptr(dl), hip.ptr(status), H, W, hip.ptr(out), hip.stream()),
               "mccnn_interpolate")
     return out
 
 
-def subpixel(dl, vol):
+def subpixel(dl, vol, out=None):
     D, H, W = vol.shape
-    out = torch.empty_like(dl)
+    out = out if out is not None else torch.empty_like(dl)
     hip.check(hip.load().mccnn_subpixel(hip.ptr(dl), hip.ptr(vol), D, H, W, hip.ptr(out), hip.stream()),
               "mccnn_subpixel")
     return out
 
 
-def median(dl, fh, fw):
+def median(dl, fh, fw, out=None):
     H, W = dl.shape
-    out = torch.empty_like(dl)
+    out = out if out is not None else torch.empty_like(dl)
     hip.check(hip.load().mccnn_median(hip.ptr(dl), H, W, int(fh), int(fw), hip.ptr(out), hip.stream()),
               "mccnn_median")
     return out
@@ -297,10 +302,22 @@ def bilateral_table(filter_height, filter_width, mean, std_dev):
     return tab
 
 
-def bilateral(image, dl, fh, fw, mean, std_dev, blur_threshold):
+_TABLES = {}   # (fh, fw, mean, std_dev, device) -> device table: built once, not per pair
+
+
+def bilateral_table_device(fh, fw, mean, std_dev, device):
+    key = (int(fh), int(fw), float(mean), float(std_dev), str(device))
+    tab = _TABLES.get(key)
+    if tab is None:
+        tab = torch.from_numpy(bilateral_table(int(fh), int(fw), mean, std_dev)).to(device)
+        _TABLES[key] = tab
+    return tab
+
+
+def bilateral(image, dl, fh, fw, mean, std_dev, blur_threshold, out=None):
     H, W = dl.shape
-    tab = torch.from_numpy(bilateral_table(int(fh), int(fw), mean, std_dev)).to(dl.device)
-    out = torch.empty_like(dl)
+    tab = bilateral_table_device(fh, fw, mean, std_dev, dl.device)
+    out = out if out is not None else torch.empty_like(dl)
     hip.check(hip.load().mccnn_bilateral(hip.ptr(image), hip.ptr(dl), H, W, int(fh), int(fw), hip.ptr(tab),
                                          _f32(blur_threshold), hip.ptr(out), hip.stream()), "mccnn_bilateral")
     return out
@@ -328,6 +345,7 @@ class StereoMatcher(object):
         self.cv_mode = cv_mode
         self.cbca_order = cbca_order
         self._ws = {}
+        self._graphs = {}
 
     def workspace(self, H, W, D):
         key = (H, W, D)
@@ -342,8 +360,13 @@ class StereoMatcher(object):
                 t1=torch.empty((n,), dtype=torch.float32, device=dev),
                 t2=torch.empty((n,), dtype=torch.float32, device=dev),
                 scratch=sgm_scratch(H, W, D, dev),
+                sup_l=support_buffer(H, W, dev), sup_r=support_buffer(H, W, dev),
+                status=torch.empty((H, W), dtype=torch.int32, device=dev),
+                maps=torch.empty((6, H, W), dtype=torch.float32, device=dev),   # dl, dr, interp, subpixel, median, out
             )
+            bilateral_table_device(5, 5, 0, self.hp["blur_sigma"], dev)
             self._ws = {key: ws}  # one shape resident at a time
+            self._graphs = {}
         return ws
 
     def match(self, left_image, right_image, ndisp, timer=_NO_TIMER, keep=None):
@@ -371,8 +394,8 @@ class StereoMatcher(object):
             keep["cv"] = (lcv.clone(), rcv.clone())
 
         timer.start("cross_arms")
-        sup_l = cross_arms(L, hp["cbca_intensity"], hp["cbca_distance"])
-        sup_r = cross_arms(R, hp["cbca_intensity"], hp["cbca_distance"])
+        sup_l = cross_arms(L, hp["cbca_intensity"], hp["cbca_distance"], out=ws["sup_l"])
+        sup_r = cross_arms(R, hp["cbca_intensity"], hp["cbca_distance"], out=ws["sup_r"])
         timer.stop()
 
         t1d, t2d = ws["t1"][:nd].view(dhw), ws["t2"][:nd].view(dhw)
@@ -401,20 +424,54 @@ class StereoMatcher(object):
         if keep is not None:
             keep["cbca2"] = (lcv.clone(), rcv.clone())
 
+        # per-pair maps live in the workspace unless the caller keeps intermediates (tests): a pair then allocates
+        # nothing but the conv activations and never blocks the host
+        m = ws["maps"] if keep is None else torch.empty_like(ws["maps"])
         timer.start("wta")
-        dl = wta(lcv)
-        dr = wta(rcv)
+        dl = wta(lcv, out=m[0])
+        dr = wta(rcv, out=m[1])
         timer.stop()
         timer.start("post")
-        st = lr_status(dl, dr, D)
-        di = interpolate(dl, st)
-        ds = subpixel(di, lcv)
-        dm = median(ds, 5, 5)
-        db = bilateral(L, dm, 5, 5, 0, hp["blur_sigma"], hp["blur_threshold"])
+        st = lr_status(dl, dr, D, out=ws["status"] if keep is None else None)
+        di = interpolate(dl, st, out=m[2])
+        ds = subpixel(di, lcv, out=m[3])
+        dm = median(ds, 5, 5, out=m[4])
+        db = bilateral(L, dm, 5, 5, 0, hp["blur_sigma"], hp["blur_threshold"], out=m[5])
         timer.stop()
         if keep is not None:
             keep.update(wta=(dl, dr), status=st, interp=di, subpixel=ds, median=dm, bilateral=db)
         return db
+
+    def match_graph(self, left_image, right_image, ndisp):
+        """match() replayed as ONE hipGraph launch: the ~75 kernel launches of a pair are captured once per image
+        shape (after two eager warm-up pairs, so MIOpen has chosen its kernels and the allocator its blocks) and
+        replayed on static input/output buffers.  Returns the static output map [H,W] (overwritten by the next
+        call).  The images are copied into the static inputs in stream order; nothing synchronises."""
+        L = left_image.reshape(left_image.shape[0], left_image.shape[1])
+        R = right_image.reshape(right_image.shape[0], right_image.shape[1])
+        key = (L.shape[0], L.shape[1], int(ndisp))
+        g = self._graphs.get(key)
+        if g is None:
+            self.workspace(*key)                 # may reset self._graphs: one shape resident at a time
+            sl, sr = torch.empty_like(L, dtype=torch.float32), torch.empty_like(R, dtype=torch.float32)
+            sl.copy_(L)
+            sr.copy_(R)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self.match(sl, sr, ndisp)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.match(sl, sr, ndisp)
+            g = (graph, sl, sr, out)
+            self._graphs[key] = g
+        graph, sl, sr, out = g
+        sl.copy_(L)
+        sr.copy_(R)
+        graph.replay()
+        return out
 
     @staticmethod
     def _as_hwd(spare_dhw, ws, hwd, nh):

@@ -86,17 +86,13 @@ def saveTimeFile(times, path):
 
 
 def testMk(dirName):
-    if not os.path.isdir(dirName):
-        os.mkdir(dirName)
+    """util.py:77-79, made safe for several ranks creating the same directory at once."""
+    os.makedirs(dirName, exist_ok=True)
 
 
 def recurMk(path):
-    """util.py:81-86 - mkdir -p, component by component from '/'."""
-    items = path.split("/")
-    prefix = "/"
-    for item in items:
-        prefix = os.path.join(prefix, item)
-        testMk(prefix)
+    """util.py:81-86 - mkdir -p."""
+    os.makedirs(path if os.path.isabs(path) else os.path.join("/", path), exist_ok=True)
 
 
 def read_gray(path):
@@ -108,6 +104,12 @@ def read_gray(path):
             im = im.convert("L")
         return np.asarray(im, dtype=np.uint8)
     rgb = np.asarray(im.convert("RGB"), dtype=np.uint32)
-    # libpng png_set_rgb_to_gray(1, 0.299, 0.587): 15-bit fixed point, coefficients 9798 / 19235 / 3735
-    gray = (rgb[:, :, 0] * 9798 + rgb[:, :, 1] * 19235 + rgb[:, :, 2] * 3735 + 16384) >> 15
+    # What OpenCV's PNG reader asks of libpng for IMREAD_GRAYSCALE: png_set_rgb_to_gray(png, 1, 0.299, 0.587).  libpng
+    # turns the two weights into 15-bit integers by truncation (29900 * 32768 / 100000 = 9797, 58700 * 32768 / 100000
+    # = 19234, blue = 32768 - 9797 - 19234 = 3737) and its 8-bit path truncates the weighted sum as well
+    # (pngrtran.c, png_set_rgb_to_gray_fixed / png_do_rgb_to_gray: "(rc*red + gc*green + bc*blue) >> 15").
+    # Pinned against the real libpng (1.6.37, decoding as OpenCV's PngDecoder sets it up) by the fixtures
+    # tests/golden/png_color_*.png / png_gray_*.npy (generator: tests/golden/gen_png_gray.c); cv2 itself is not in
+    # this image, so its own share (the call above) stays unpinned.
+    gray = (rgb[:, :, 0] * 9797 + rgb[:, :, 1] * 19234 + rgb[:, :, 2] * 3737) >> 15
     return gray.astype(np.uint8)

@@ -39,7 +39,7 @@ def test_match_cli_writes_reference_outputs(tmp_path, net_layers):
     lst.write_text("".join("%s/im0.png\n" % (data / rel) for rel in rels))
     cmd = [sys.executable, os.path.join(ROOT, "mc-cnn-python_amd", "src", "match.py"), "-g", "0",
            "--list_file", str(lst), "--resume", os.path.join(GOLDEN_DIR, "mccnn_fast_weights.npz"),
-           "--data_dir", str(data), "--save_dir", str(out), "-t", "t1", "-s", "0", "-e", "1", "--exact"]
+           "--data_dir", str(data), "--save_dir", str(out), "-t", "t1", "-s", "0", "-e", "1"]   # default: bit-exact
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0, r.stdout.decode()[-2000:]
     for rel in rels:
@@ -80,3 +80,62 @@ def test_bench_two_ranks_share_one_gpu():
     # value = 2 ranks x 256*256*64 voxels x 3 steps / (max-rank seconds): consistent with ms_per_step
     want = 2 * 256 * 256 * 64 * 1e-6 / (d["ms_per_step"] * 1e-3)
     assert abs(d["value"] - want) <= 0.02 * want
+
+
+def test_bench_world_size_one_through_rccl():
+    """bench.py with the process group forced on at world size 1 (MCCNN_BENCH_FORCE_DIST=1): backend "nccl" = RCCL is
+    initialised with a device id, and the barrier + all_gather of the multi-GPU path run on a device tensor - what an
+    8-GPU launch does per rank, minus the peers.  Also checks the JSON contract of the default (hipGraph) launch mode."""
+    import json
+    env = dict(os.environ, MCCNN_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29633", RANK="0",
+               LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--config",
+           "cfg1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["process_group"] == "nccl x1", d["process_group"]
+    assert d["n_gpus"] == 1 and d["config"]["launch"] == "one hipGraph replay per pair"
+    assert d["roofline"]["kernel"] == "cbca_iter" and 0.0 < d["roofline"]["frac"] < 1.5
+    want = 256 * 256 * 64 * 1e-6 / (d["ms_per_step"] * 1e-3)
+    assert abs(d["value"] - want) <= 0.02 * want
+    assert d["ms_per_step_host_in_host_out"] > 0 and d["ms_per_step_kernel_by_kernel"] > 0
+
+
+def test_match_cli_two_ranks_write_disjoint_complete_outputs(tmp_path):
+    """match.py under torch.distributed.run with two ranks (sharing the one GPU of the test box): rank r takes the pairs
+    i = r (mod 2) of the window; together they write every pair exactly once, and what they write equals a single-rank
+    run of the same command bit for bit."""
+    data = tmp_path / "data"
+    H, W, D = 32, 48, 8
+    rels = ["setA/p%d" % i for i in range(5)]
+    for i, rel in enumerate(rels):
+        _write_pair(str(data / rel), H, W, D, seed=40 + i)
+    lst = tmp_path / "list.txt"
+    lst.write_text("".join("%s/im0.png\n" % (data / rel) for rel in rels))
+    common = ["--list_file", str(lst), "--resume", os.path.join(GOLDEN_DIR, "mccnn_fast_weights.npz"),
+              "--data_dir", str(data), "-s", "1", "-e", "4"]
+    script = os.path.join(ROOT, "mc-cnn-python_amd", "src", "match.py")
+    env = dict(os.environ, MCCNN_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
+    two = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29635", script] + common + ["--save_dir", str(tmp_path / "two"), "-t", "r"]
+    r = subprocess.run(two, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    log = r.stdout.decode()
+    import re
+    owners = {}
+    for rk, idx in re.findall(r"\[(\d+)\] pair (\d+):", log):      # the two ranks' lines may interleave
+        owners.setdefault(int(idx), []).append(int(rk))
+    assert owners == {1: [0], 2: [1], 3: [0], 4: [1]}, owners          # window [1,4], round-robin from its start
+    one = [sys.executable, script] + common + ["-g", "0", "--save_dir", str(tmp_path / "one"), "-t", "r"]
+    r = subprocess.run(one, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    assert not (tmp_path / "two" / "submit_r" / rels[0]).exists()      # index 0 is outside the window
+    for rel in rels[1:]:
+        for root, name in (("submit_r", "disp0MCCNN.pfm"), ("submit_r_imgs", "disp0MCCNN.pgm")):
+            a = (tmp_path / "two" / root / rel / name).read_bytes()
+            b = (tmp_path / "one" / root / rel / name).read_bytes()
+            assert a == b and len(a) > H * W, (rel, name)
+        assert float((tmp_path / "two" / "submit_r" / rel / "timeMCCNN.txt").read_text()) > 0

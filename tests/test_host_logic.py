@@ -4,6 +4,8 @@ import os
 import struct
 
 import numpy as np
+
+from conftest import GOLDEN_DIR
 import pytest
 import torch
 
@@ -141,6 +143,53 @@ def test_read_gray(tmp_path):
     got = util.read_gray(str(tmp_path / "c.png")).astype(int)
     lum = 0.299 * rgb[:, :, 0] + 0.587 * rgb[:, :, 1] + 0.114 * rgb[:, :, 2]
     assert np.abs(got - lum).max() <= 1.0
+
+
+def test_read_gray_matches_libpng_fixture():
+    """Colour PNGs decoded to grey by the REAL libpng 1.6.37 set up as OpenCV's reader sets it up for IMREAD_GRAYSCALE
+    (tests/golden/gen_png_gray.c, run in the build container): util.read_gray must give the same bytes."""
+    import util
+    for name in ("rgb", "rgba"):
+        want = np.load(os.path.join(GOLDEN_DIR, "png_gray_%s.npy" % name))
+        got = util.read_gray(os.path.join(GOLDEN_DIR, "png_color_%s.png" % name))
+        assert got.dtype == np.uint8 and np.array_equal(got, want), name
+    # and the arithmetic spelled out once more, independently of util: truncating 15-bit weights 9797 / 19234 / 3737
+    from PIL import Image
+    rgb = np.asarray(Image.open(os.path.join(GOLDEN_DIR, "png_color_rgb.png")).convert("RGB")).astype(np.int64)
+    want = np.load(os.path.join(GOLDEN_DIR, "png_gray_rgb.npy"))
+    for y, x in ((0, 0), (9, 17), (23, 39), (12, 5)):
+        r, g, b = (int(v) for v in rgb[y, x])
+        assert (r * 9797 + g * 19234 + b * 3737) >> 15 == int(want[y, x])
+
+
+def test_drop_in_defaults_are_the_bit_exact_variants():
+    import match
+    import process_functional as pf
+    assert pf.COST_VOLUME_MODE == "exact" and pf.CBCA_ORDER == "reference"
+    base = ["--list_file", "l", "--data_dir", "d", "--save_dir", "s", "-t", "x", "-s", "0", "-e", "3"]
+    assert match.parser.parse_args(base).fast is False
+    assert match.parser.parse_args(base + ["--fast"]).fast is True
+
+
+def test_recurmk_survives_concurrent_creation(tmp_path):
+    """Several ranks create the same output tree at once (match.py under torchrun): no check-then-create race."""
+    import threading
+    import util
+    target = str(tmp_path / "submit_t" / "a" / "b")
+    errors = []
+
+    def work():
+        try:
+            for _ in range(50):
+                util.recurMk(target)
+                util.testMk(target)
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=work) for _ in range(8)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors and os.path.isdir(target)
 
 
 def test_cli_flags_match_reference():

@@ -560,3 +560,23 @@ def test_abi_error_behaviour(sd):
         hip.check(lib.mccnn_wta(None, 4, 8, 16, hip.ptr(img), s), "mccnn_wta")
     with pytest.raises(ValueError):
         sd.cbca(v, out, sup.clone(), 1, 14)      # a copy of the support tensor has lost its second plane
+
+
+def test_graph_replay_equals_kernel_by_kernel(sd, net_layers):
+    """StereoMatcher.match_graph (one hipGraph launch per pair, static buffers) against match() on three different
+    pairs of one shape, fast and exact variants: bit-identical maps, and the replay really reuses its capture."""
+    import _hipabi as hip
+    import synthetic
+    from model import NET
+    H, W, D = 64, 96, 24
+    net = NET(None, input_patch_size=11, batch_size=1, device="cuda").set_layers(net_layers)
+    for cv, order in ((hip.MCCNN_CV_MFMA, hip.MCCNN_CBCA_SEPARABLE), (hip.MCCNN_CV_EXACT, hip.MCCNN_CBCA_REFERENCE_ORDER)):
+        m = sd.StereoMatcher(net, cv_mode=cv, cbca_order=order)
+        for seed in (1, 2, 3):
+            L, R, _, _, _ = synthetic.make_pair(H, W, D, seed=seed)
+            l, r = dev(L[:, :, 0]), dev(R[:, :, 0])
+            want = m.match(l, r, D).clone()
+            got = m.match_graph(l, r, D)
+            torch.cuda.synchronize()
+            assert np.array_equal(got.cpu().numpy(), want.cpu().numpy(), equal_nan=True), (cv, order, seed)
+        assert len(m._graphs) == 1
