@@ -1,0 +1,206 @@
+"""GPU: parity at the sizes of BASELINE.json's configs.
+
+cfg1 (256x256, D=64) is small enough for the CPU checker to follow a WHOLE pair stage by stage (each stage of the GPU
+run is fed, on the CPU, the GPU's own output of the stage before - identical inputs, so the bit-exact variants must be
+bit-identical and the fast variants stay within their stated per-stage tolerance).  The measured differences are written
+to gpurun_out/parity_r02.json (copied to profiles/ by hand) so that the numbers behind the bounds are on record.
+cfg3 (1242x375, D=192) gets the size-independent properties and an oracle window at its full width.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from helpers import assert_bits
+
+pytestmark = pytest.mark.gpu
+
+RECORD = {}
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _dump():
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "parity_r02.json"), "w") as f:
+            json.dump(RECORD, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def _stagewise(keep, L, R, D, o, exact):
+    """Feeds every GPU stage output to the CPU checker's next stage; returns {stage: max |gpu - cpu|} (0.0 = all bits
+    equal) and the CPU results of the last stages."""
+    hp = dict(tau=0.02, dist=14)
+    d = {}
+
+    def diff(a, b):
+        a = a.cpu().numpy() if torch.is_tensor(a) else a
+        return 0.0 if np.array_equal(a, b, equal_nan=True) else float(np.nanmax(np.abs(a.astype(np.float64) - b)))
+
+    cv = [t.cpu().numpy() for t in keep["cv"]]
+    c1 = o.cost_volume_aggregation(L, R, cv[0], cv[1], hp["tau"], hp["dist"], 2)
+    d["cbca_x2"] = max(diff(keep["cbca1"][0], c1[0]), diff(keep["cbca1"][1], c1[1]))
+    g1 = [t.cpu().numpy() for t in keep["cbca1"]]
+    s = o.SGM_average(g1[0].copy(), g1[1].copy(), L, R, 2.3, 55.9, 4, 8, 0.08, 1.5)
+    d["sgm"] = max(diff(keep["sgm"][0], s[0]), diff(keep["sgm"][1], s[1]))
+    gs = [t.cpu().numpy() for t in keep["sgm"]]
+    c2 = o.cost_volume_aggregation(L, R, gs[0], gs[1], hp["tau"], hp["dist"], 16)
+    d["cbca_x16"] = max(diff(keep["cbca2"][0], c2[0]), diff(keep["cbca2"][1], c2[1]))
+    d["cbca_x16_spacings_of_max_input"] = d["cbca_x16"] / float(np.spacing(np.float32(np.abs(gs[0]).max())))
+    g2 = [t.cpu().numpy() for t in keep["cbca2"]]
+    dl, dr = o.disparity_prediction(g2[0], g2[1])
+    d["wta_mismatches"] = int((keep["wta"][0].cpu().numpy() != dl).sum() + (keep["wta"][1].cpu().numpy() != dr).sum())
+    gdl, gdr = keep["wta"][0].cpu().numpy(), keep["wta"][1].cpu().numpy()
+    di = o.interpolation(gdl, gdr, D)
+    d["interpolation"] = diff(keep["interp"], di)
+    ds = o.subpixel_enhance(keep["interp"].cpu().numpy(), g2[0])
+    d["subpixel"] = diff(keep["subpixel"], ds)
+    dm = o.median_filter(keep["subpixel"].cpu().numpy(), 5, 5)
+    d["median"] = diff(keep["median"], dm)
+    db = o.bilateral_filter(L, keep["median"].cpu().numpy(), 5, 5, 0, 6, 2)
+    d["bilateral"] = diff(keep["bilateral"], db)
+    return d
+
+
+def test_cfg1_whole_pair_stage_by_stage(net_layers):
+    """BASELINE cfg1, one synthetic pair through the whole timed region, both variants."""
+    import _hipabi as hip
+    import oracle as o
+    import stereo_device as sd
+    import synthetic
+    from model import NET
+    H, W, D = 256, 256, 64
+    L, R, _, _, _ = synthetic.make_pair(H, W, D, seed=11)
+    net = NET(None, input_patch_size=11, batch_size=1, device="cuda").set_layers(net_layers)
+
+    # bit-exact variants: every stage after the features bit-identical given the GPU's own previous output
+    m = sd.StereoMatcher(net, cv_mode=hip.MCCNN_CV_EXACT, cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER)
+    keep = {}
+    exact_map = m.match(dev(L), dev(R), D, keep=keep).cpu().numpy()
+    fl = net.features_pair_hwc(dev(L[:, :, 0]), dev(R[:, :, 0]))
+    ocv = o.compute_cost_volume(fl[0].cpu().numpy(), fl[1].cpu().numpy(), D)
+    assert_bits(keep["cv"][0].cpu().numpy(), ocv[0], "cfg1 cost volume L")
+    assert_bits(keep["cv"][1].cpu().numpy(), ocv[1], "cfg1 cost volume R")
+    d = _stagewise(keep, L, R, D, o, exact=True)
+    RECORD["cfg1_exact_stagewise_max_abs"] = d
+    bad = {k: v for k, v in d.items() if v != 0}
+    assert not bad, "bit-exact variants differ from the CPU checker: %s" % bad
+    exact_wta = keep["wta"][0].cpu().numpy()
+    ofl = o.net_features(L, net_layers)
+    RECORD["cfg1_features_max_abs_vs_float64_restatement"] = float(np.abs(fl[0].cpu().numpy() - ofl).max())
+    assert RECORD["cfg1_features_max_abs_vs_float64_restatement"] <= 1e-5
+
+    # fast variants: per-stage tolerance against the CPU checker on identical inputs, then against the exact run
+    m = sd.StereoMatcher(net, cv_mode=hip.MCCNN_CV_MFMA, cbca_order=hip.MCCNN_CBCA_SEPARABLE)
+    keep = {}
+    fast_map = m.match(dev(L), dev(R), D, keep=keep).cpu().numpy()
+    cv_err = max(float(np.abs(keep["cv"][0].cpu().numpy() - ocv[0]).max()),
+                 float(np.abs(keep["cv"][1].cpu().numpy() - ocv[1]).max()))
+    d = _stagewise(keep, L, R, D, o, exact=False)
+    d["cost_volume_mfma"] = cv_err
+    flips = int((keep["wta"][0].cpu().numpy() != exact_wta).sum())
+    close = float(np.isclose(fast_map, exact_map, atol=1e-3, equal_nan=True).mean())
+    RECORD["cfg1_fast_stagewise_max_abs"] = d
+    RECORD["cfg1_fast_vs_exact"] = {"wta_flips": flips, "pixels": int(fast_map.size),
+                                    "fraction_within_1e-3_px": close,
+                                    "max_abs_px": float(np.nanmax(np.abs(fast_map - exact_map)))}
+    _dump()
+    assert cv_err <= 2e-6
+    assert d["cbca_x2"] <= 2 * 8 * float(np.spacing(np.float32(1.0)))          # <= 8 spacings of max|input| per iteration
+    # 16 iterations on post-SGM costs (|v| up to ~200), regions up to 729 pixels: measured 60 spacings of max|input|
+    # (9.2e-4 absolute) - the reference's flat float32 running sum is what deviates from the correctly rounded mean
+    assert d["cbca_x16_spacings_of_max_input"] <= 8.0 * 16
+    for k in ("sgm", "interpolation", "subpixel", "median", "bilateral"):       # these stages have no fast variant
+        assert d[k] == 0.0, (k, d[k])
+    assert d["wta_mismatches"] == 0
+    assert flips <= fast_map.size // 500, "fast variants flip %d WTA decisions of %d" % (flips, fast_map.size)
+    assert close >= 0.985, "only %.4f of the pixels within 1e-3 px of the bit-exact run" % close
+
+
+def test_cfg3_full_size_properties():
+    """KITTI-sized volume (1242x375, D=192): 6 strips per plane, 13 px of the last one; D < 256 takes the partial
+    SGM kernels; the CBCA launch heuristic cuts the rows into chunks."""
+    import _hipabi as hip
+    import stereo_device as sd
+    H, W, D = 375, 1242, 192
+    g = torch.Generator(device="cuda").manual_seed(7)
+    v = -torch.rand((D, H, W), device="cuda", generator=g)
+    hwd = sd.dhw_to_hwd(v)
+    assert torch.equal(sd.hwd_to_dhw(hwd, D), v)
+    assert torch.equal(sd.wta(v), torch.argmin(v, dim=0).float())
+    img = torch.rand((H, W), device="cuda", generator=g)
+    img = torch.nn.functional.avg_pool2d(img[None, None], 9, 1, 4)[0, 0].contiguous()   # smooth: long arms
+    sup = sd.cross_arms(img, 0.02, 14)
+    assert int(sd.support_count(sup).max()) > 200
+    # partition of unity + streaming vs reference-order kernel on sampled planes (incl. the first and the last)
+    c = torch.full((6, H, W), -0.375, device="cuda")
+    res, _ = sd.cbca(c, torch.empty_like(c), sup, 2, 14)
+    assert torch.equal(res, torch.full_like(res, -0.375))
+    fast, _ = sd.cbca(v.clone(), torch.empty_like(v), sup, 1, 14, hip.MCCNN_CBCA_SEPARABLE)
+    idx = [0, 1, 63, 64, 100, 190, 191]
+    vs = v[idx].contiguous()
+    ref, _ = sd.cbca(vs.clone(), torch.empty_like(vs), sup, 1, 14, hip.MCCNN_CBCA_REFERENCE_ORDER)
+    err = float((fast[idx] - ref).abs().max())
+    RECORD["cfg3_streaming_vs_reference_order_max_abs"] = err
+    assert err <= 8 * float(np.spacing(np.float32(1.0))), err
+    # fused first pass == layout change + pass, both sides (D = 192: the partial-width kernel)
+    il, ir = img, torch.rand((H, W), device="cuda", generator=g)
+    vr = -torch.rand((D, H, W), device="cuda", generator=g)
+    scratch = sd.sgm_scratch(H, W, D, v.device)
+    hp = dict(sgm_P1=2.3, sgm_P2=55.9, sgm_Q1=4.0, sgm_Q2=8.0, sgm_D=0.08, sgm_V=1.5)
+    fused = [torch.empty((H, W, sd.hwd_pitch(D)), device="cuda") for _ in range(2)]
+    sd.sgm_average_from_dhw(il, ir, [v, vr], fused, [0, 1], D, scratch=scratch, **hp)
+    plain = [sd.dhw_to_hwd(v), sd.dhw_to_hwd(vr)]
+    sd.sgm_average_hwd(il, ir, plain, [0, 1], D, scratch=scratch, **hp)
+    assert torch.equal(fused[0], plain[0]) and torch.equal(fused[1], plain[1])
+    # SGM shift invariance on exactly representable costs
+    vi = torch.randint(0, 64, (D, H, W), device="cuda", generator=g).float()
+    q = (img * 4).round() / 4
+    outs = []
+    for shift in (0.0, 32.0):
+        h = sd.dhw_to_hwd(vi + shift)
+        sd.sgm_pass_hwd(q, q, [h], [hip.MCCNN_SIDE_RIGHT], D, (0, -1), 2.0, 56.0, 4.0, 8.0, 0.08, scratch)
+        sd.sgm_pass_hwd(q, q, [h], [hip.MCCNN_SIDE_RIGHT], D, (1, 0), 2.0, 56.0, 4.0, 8.0, 0.08, scratch)
+        outs.append(sd.hwd_to_dhw(h, D))
+    assert torch.equal(outs[1], outs[0] + 32.0)
+    _dump()
+
+
+def test_cfg3_width_oracle_window():
+    """A 1242-wide, 14-row, D=24 window through every volume stage against the CPU checker (six strips per plane, the
+    last one 122 columns; row count below one row chunk)."""
+    import oracle as o
+    import process_functional as pf
+    import synthetic
+    H, W, D = 14, 1242, 24
+    rng = np.random.default_rng(3)
+    L, R, _, _, _ = synthetic.make_pair(H, W, D, seed=9)
+    vl = (-rng.random((D, H, W), dtype=np.float32)).astype(np.float32)
+    vr = (-rng.random((D, H, W), dtype=np.float32)).astype(np.float32)
+    ol, orr = o.cost_volume_aggregation(L, R, vl, vr, 0.02, 14, 2)
+    pf.CBCA_ORDER = "reference"
+    gl, gr = pf.cost_volume_aggregation(L, R, vl, vr, 0.02, 14, 2)
+    assert_bits(gl, ol, "cbca reference order, W=1242")
+    assert_bits(gr, orr, "cbca reference order, W=1242 (right)")
+    pf.CBCA_ORDER = "separable"
+    try:
+        sl, sr = pf.cost_volume_aggregation(L, R, vl, vr, 0.02, 14, 2)
+    finally:
+        pf.CBCA_ORDER = "reference"
+    assert max(np.abs(sl - ol).max(), np.abs(sr - orr).max()) <= 2 * 8 * float(np.spacing(np.float32(1.0)))
+    a = o.SGM_average(ol.copy(), orr.copy(), L, R, 2.3, 55.9, 4, 8, 0.08, 1.5)
+    b = pf.SGM_average(ol.copy(), orr.copy(), L, R, 2.3, 55.9, 4, 8, 0.08, 1.5)
+    assert_bits(b[0], a[0], "SGM_average, W=1242")
+    assert_bits(b[1], a[1], "SGM_average, W=1242 (right)")
+    odl, odr = o.disparity_prediction(a[0], a[1])
+    gdl, gdr = pf.disparity_prediction(a[0], a[1])
+    assert_bits(gdl, odl, "wta W=1242")
+    assert_bits(pf.interpolation(gdl, gdr, D), o.interpolation(odl, odr, D), "interpolation W=1242")

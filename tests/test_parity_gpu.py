@@ -6,7 +6,8 @@ Tolerances:
   bit-exact   cost volume (exact mode), arms/counts, CBCA (reference order), every SGM pass, WTA index, LR/interp,
               sub-pixel, median, bilateral
   <= 2e-6     cost volume on the matrix cores (fma-chain order instead of NumPy's pairwise order)
-  <= 1e-6/it  CBCA separable order (same set, different float32 association)
+  <= 8 spacings of max|input| for one iteration, <= 2 per iteration over many - CBCA separable order (the correctly
+              rounded mean against the reference's flat float32 running sum)
   <= 1e-5     features vs the float64-accumulating restatement (TensorFlow parity itself is unpinned)
 """
 import numpy as np
@@ -101,13 +102,18 @@ def test_golden_cbca_separable_tolerance(pf, golden_cases):
     for name, g in golden_cases:
         hp = hp_of(g)
         tau, dist = hp["cbca_intensity"], hp["cbca_distance"]
+        # The streaming kernel returns the correctly rounded region mean; the reference's flat float32 running sum is
+        # what carries the difference.  Bound in units of the float32 spacing at the largest input magnitude (the
+        # summands' scale): <= 8 spacings for one iteration (measured <= 5), <= 2 per iteration over 16 (measured <= 18
+        # in total at |costs| up to 160).
         l, r = pf.cost_volume_aggregation(g["left"], g["right"], g["cv_l"], g["cv_r"], tau, dist, 1)
-        assert np.abs(l - g["cbca1it_l"]).max() <= 1e-6, name
-        assert np.abs(r - g["cbca1it_r"]).max() <= 1e-6, name
+        sp = float(np.spacing(np.float32(max(np.abs(g["cv_l"]).max(), np.abs(g["cv_r"]).max()))))
+        assert np.abs(l - g["cbca1it_l"]).max() <= 8 * sp, name
+        assert np.abs(r - g["cbca1it_r"]).max() <= 8 * sp, name
         l, r = pf.cost_volume_aggregation(g["left"], g["right"], g["sgm_l"], g["sgm_r"], tau, dist, hp["it2"])
-        scale = max(1.0, float(np.abs(g["sgm_l"]).max()))
-        assert np.abs(l - g["cbca2_l"]).max() <= 16e-6 * scale, name   # 16 iterations, O(scale) costs
-        assert np.abs(r - g["cbca2_r"]).max() <= 16e-6 * scale, name
+        sp = float(np.spacing(np.float32(max(np.abs(g["sgm_l"]).max(), np.abs(g["sgm_r"]).max()))))
+        assert np.abs(l - g["cbca2_l"]).max() <= 2 * hp["it2"] * sp, name
+        assert np.abs(r - g["cbca2_r"]).max() <= 2 * hp["it2"] * sp, name
 
 
 def test_golden_sgm_each_direction_bit_exact(pf, golden_cases):
@@ -171,8 +177,9 @@ def test_golden_whole_pair_reference_order(sd, golden_cases, net_layers):
         out = m.match(dev(g["left"]), dev(g["right"]), D, keep=keep).cpu().numpy()
         flips = int((keep["wta"][0].cpu().numpy() != g["wta_l"]).sum())
         close = np.isclose(out, g["bilateral"], atol=1e-3, equal_nan=True).mean()
-        assert flips <= max(2, out.size // 100), "%s: %d WTA flips" % (name, flips)
-        assert close >= 0.97, "%s: only %.3f of pixels within 1e-3 px" % (name, close)
+        # measured on the four golden pairs: 0 flips, every pixel within 1e-3 px (features differ by <= 4e-7)
+        assert flips <= 2, "%s: %d WTA flips" % (name, flips)
+        assert close >= 0.999, "%s: only %.4f of pixels within 1e-3 px" % (name, close)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -477,8 +484,10 @@ def test_golden_whole_pair_fast_variants(sd, golden_cases, net_layers):
         out = m.match(dev(g["left"]), dev(g["right"]), D, keep=keep).cpu().numpy()
         flips = int((keep["wta"][0].cpu().numpy() != g["wta_l"]).sum())
         close = np.isclose(out, g["bilateral"], atol=1e-3, equal_nan=True).mean()
-        assert flips <= max(2, out.size // 100), "%s: %d WTA flips" % (name, flips)
-        assert close >= 0.97, "%s: only %.3f of pixels within 1e-3 px" % (name, close)
+        # measured: 0 flips on all four pairs; >= 98.85 % of the pixels within 1e-3 px (the sub-pixel parabola
+        # amplifies 1e-6 cost differences where its denominator is small; largest difference 0.004 px)
+        assert flips <= 2, "%s: %d WTA flips" % (name, flips)
+        assert close >= 0.985, "%s: only %.4f of pixels within 1e-3 px" % (name, close)
 
 
 def _random_shapes(n, seed):

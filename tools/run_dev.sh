@@ -1,1 +1,2 @@
 timeout 1700 python -m pytest tests -m gpu -x -q 2>&1 | tail -15
+cat gpurun_out/parity_r02.json
