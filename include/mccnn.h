@@ -123,7 +123,9 @@ int mccnn_sgm_first_pass(const float *image_left, const float *image_right, cons
                          float *const *vol_hwd, const int *side, int n_jobs, int D, int H, int W, float p1, float p2,
                          float q1, float q2, float thr, void *scratch, size_t scratch_bytes, mccnn_stream_t stream);
 
-/* ---- a7  disparity_prediction, one volume (pf:239-272): first strict minimum over d, as float32 -------------- */
+/* ---- a7  disparity_prediction, one volume (pf:239-272): first strict minimum over d, as float32 --------------
+ * A pixel whose D costs are all NaN / +inf gets -1 (the reference asserts there, pf:253); mccnn_lr_status treats a
+ * negative or NaN disparity as an occlusion. */
 int mccnn_wta(const float *vol_dhw, int D, int H, int W, float *disparity, mccnn_stream_t stream);
 
 /* ---- a8  interpolation (pf:279-378) -------------------------------------------------------------------------

@@ -38,10 +38,14 @@ __global__ __launch_bounds__(256) void lr_status_kernel(const float *__restrict_
     const int h = blockIdx.y;
     if (w >= W) return;
     const float *drow = dr + (size_t)h * W;
-    const int ld = (int)dl[(size_t)h * W + w];  // pf:287 int() truncation
+    const float lf = dl[(size_t)h * W + w];
+    const int ld = (int)lf;  // pf:287 int() truncation
     int st;
-    if (w < ld) {
-        st = 2;  // pf:289-291
+    if (!(lf >= 0.f) || w < ld) {
+        // pf:289-291.  A negative or NaN disparity cannot come out of the reference (its WTA asserts a finite minimum,
+        // pf:253); mccnn_wta writes -1 for a pixel whose costs are all NaN/+inf, and such a pixel is treated as occluded
+        // here instead of indexing the right map out of bounds.
+        st = 2;
     } else if (fabsf((float)ld - drow[w - ld]) <= 1.f) {
         st = 0;  // pf:294
     } else {
