@@ -70,7 +70,7 @@ class NET(object):
         return self
 
     def get_layers(self):
-        return [(np.ascontiguousarray(w.permute(2, 3, 1, 0).cpu().numpy()), b.cpu().numpy())
+        return [(np.ascontiguousarray(w.detach().permute(2, 3, 1, 0).cpu().numpy()), b.detach().cpu().numpy())
                 for w, b in zip(self.weights, self.biases)]
 
     def restore(self, checkpoint):
@@ -158,15 +158,38 @@ class NET(object):
         out = self._convs_device(image_hw[None], pad)[0]      # [64,H,W] without the last bias
         return stereo_device.l2norm_chw_to_hwc(out, self.biases[-1])
 
-    def features_pair_hwc(self, left_hw, right_hw):
+    def features_pair_hwc(self, left_hw, right_hw, tile_rows=None):
         """Both views through the shared-weight stack as one batch of two (the Siamese towers are the same weights,
-        model.py:98 AUTO_REUSE / train.py:76-78): half the launches, twice the work per launch."""
+        model.py:98 AUTO_REUSE / train.py:76-78): half the launches, twice the work per launch.
+
+        tile_rows: evaluate the stack on horizontal bands of that many output rows (each band sees its (patch-1)/2
+        halo rows of the once-padded image, so every output pixel gets exactly the receptive field it has in the
+        untiled run) - the working version of the 4-quadrant scheme the reference left commented out
+        (process_functional.py:46-60) for images whose activations do not fit; peak activation memory scales with the
+        band instead of the image.  None (default): the whole image at once."""
         import stereo_device
         pad = (self.input_patch_size - 1) // 2
         assert pad == self.num_conv_layers * (self.conv_kernel_size - 1) // 2
-        out = self._convs_device(torch.stack((left_hw, right_hw)), pad)              # [2,64,H,W], last bias pending
-        return (stereo_device.l2norm_chw_to_hwc(out[0], self.biases[-1]),
-                stereo_device.l2norm_chw_to_hwc(out[1], self.biases[-1]))
+        pair = torch.stack((left_hw, right_hw))
+        if tile_rows is None or tile_rows >= pair.shape[1]:
+            out = self._convs_device(pair, pad)                                       # [2,64,H,W], last bias pending
+            return (stereo_device.l2norm_chw_to_hwc(out[0], self.biases[-1]),
+                    stereo_device.l2norm_chw_to_hwc(out[1], self.biases[-1]))
+        H, W = pair.shape[1], pair.shape[2]
+        x = F.pad(pair[:, None], (pad, pad, pad, pad))                                # zero-pad ONCE (pf:20-25)
+        feats = [torch.empty((H, W, self.num_conv_feature_maps), dtype=torch.float32, device=pair.device)
+                 for _ in range(2)]
+        for y0 in range(0, H, int(tile_rows)):
+            y1 = min(y0 + int(tile_rows), H)
+            t = x[:, :, y0:y1 + 2 * pad, :]
+            for k in range(self.num_conv_layers):
+                t = F.conv2d(t, self.weights[k], None)
+                if k < self.num_conv_layers - 1:
+                    t = stereo_device.bias_act_(t.contiguous(), self.biases[k], True)
+            t = t.contiguous()
+            for v in range(2):   # the band's unit vectors go straight into the [H,W,64] result
+                stereo_device.l2norm_chw_to_hwc(t[v], self.biases[-1], out=feats[v][y0:y1])
+        return feats[0], feats[1]
 
 
 if __name__ == "__main__":

@@ -74,10 +74,12 @@ def conv1_pad_bias_relu(images, weight, bias, pad):
     return out
 
 
-def l2norm_chw_to_hwc(chw, bias=None):
+def l2norm_chw_to_hwc(chw, bias=None, out=None):
     """[C,H,W] conv output (+ the last layer's bias) -> [H,W,C] unit feature vectors (model.py:64)."""
     C, H, W = chw.shape
-    out = torch.empty((H, W, C), dtype=torch.float32, device=chw.device)
+    if out is None:
+        out = torch.empty((H, W, C), dtype=torch.float32, device=chw.device)
+    assert tuple(out.shape) == (H, W, C) and out.is_contiguous()
     hip.check(hip.load().mccnn_l2norm_chw_to_hwc(hip.ptr(chw), hip.ptr(bias) if bias is not None else None,
                                                  hip.ptr(out), C, H, W, hip.stream()), "mccnn_l2norm_chw_to_hwc")
     return out
@@ -336,7 +338,8 @@ class StereoMatcher(object):
     cv_mode / cbca_order select the bit-exact or the fast variant of those two stages.
     """
 
-    def __init__(self, net, hp=None, cv_mode=hip.MCCNN_CV_EXACT, cbca_order=hip.MCCNN_CBCA_SEPARABLE):
+    def __init__(self, net, hp=None, cv_mode=hip.MCCNN_CV_EXACT, cbca_order=hip.MCCNN_CBCA_SEPARABLE,
+                 feature_tile_rows=None):
         self.device = hip.require_device()
         self.net = net
         self.hp = dict(DEFAULT_HP)
@@ -344,6 +347,7 @@ class StereoMatcher(object):
             self.hp.update(hp)
         self.cv_mode = cv_mode
         self.cbca_order = cbca_order
+        self.feature_tile_rows = feature_tile_rows   # None: whole image; else NET.features_pair_hwc's band height
         self._ws = {}
         self._graphs = {}
 
@@ -383,7 +387,7 @@ class StereoMatcher(object):
         nd, nh = D * H * W, H * W * hwd[2]
 
         timer.start("features")
-        fl, fr = self.net.features_pair_hwc(L, R)
+        fl, fr = self.net.features_pair_hwc(L, R, tile_rows=self.feature_tile_rows)
         timer.stop()
 
         timer.start("cost_volume")

@@ -3,9 +3,9 @@
 Only `normal` is on the timed hot path (bilateral_filter uses it, process_functional.py:428); the file I/O is what
 match.py needs around the timed region.  Image decode / PGM encode live in OpenCV + libpng in the reference
 (match.py:118-119, util.py:52); neither is in this image, so parity of those two calls is unpinned:
-  * read_gray() decodes with PIL and converts colour to grey with libpng's rgb_to_gray fixed-point weights
-    (what cv2.imread(..., IMREAD_GRAYSCALE) uses for PNG), which can differ from OpenCV by one grey level on
-    some pixels;
+  * read_gray() decodes with PIL and converts colour to grey with libpng's rgb_to_gray arithmetic (what
+    cv2.imread(..., IMREAD_GRAYSCALE) asks of libpng for a PNG) - pinned bit for bit against the real libpng 1.6.37
+    by fixtures (tests/golden/gen_png_gray.c); OpenCV itself is not in this image;
   * saveDisparity() writes the saturate-cast (round-half-even, clamp 0..255) uint8 map as binary PGM, which is what
     cv2.imwrite does with a float32 matrix.
 """

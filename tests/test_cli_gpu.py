@@ -139,3 +139,28 @@ def test_match_cli_two_ranks_write_disjoint_complete_outputs(tmp_path):
             b = (tmp_path / "one" / root / rel / name).read_bytes()
             assert a == b and len(a) > H * W, (rel, name)
         assert float((tmp_path / "two" / "submit_r" / rel / "timeMCCNN.txt").read_text()) > 0
+
+
+def test_training_step_on_the_gpu_and_weights_feed_the_matcher(net_layers):
+    """train.Trainer on cuda:0 (MIOpen forward + backward): the hinge loss of a fixed batch falls under momentum SGD,
+    and the trained weights go straight into the matching pipeline."""
+    import _hipabi as hip
+    import stereo_device as sd
+    import synthetic
+    import train
+    from model import NET
+    rng = np.random.default_rng(0)
+    base = rng.standard_normal((48, 11, 11, 1)).astype(np.float32)
+    batch = [base, base + 0.05 * rng.standard_normal(base.shape).astype(np.float32),
+             rng.standard_normal(base.shape).astype(np.float32)]
+    net = NET(None, batch_size=48, device="cuda", seed=3)
+    t = train.Trainer(net, 0.02, 0.9, 0.2)
+    losses = [t.step(*batch) for _ in range(40)]
+    assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
+    inf = NET(None, input_patch_size=11, batch_size=1, device="cuda").set_layers(net.get_layers())
+    H, W, D = 40, 64, 8
+    L, R, _, _, _ = synthetic.make_pair(H, W, D, seed=5)
+    m = sd.StereoMatcher(inf, cv_mode=hip.MCCNN_CV_EXACT, cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER)
+    import torch
+    out = m.match(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda(), D)
+    assert out.shape == (H, W) and bool(torch.isfinite(out).all())

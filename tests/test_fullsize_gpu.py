@@ -204,3 +204,37 @@ def test_cfg3_width_oracle_window():
     gdl, gdr = pf.disparity_prediction(a[0], a[1])
     assert_bits(gdl, odl, "wta W=1242")
     assert_bits(pf.interpolation(gdl, gdr, D), o.interpolation(odl, odr, D), "interpolation W=1242")
+
+
+def test_feature_row_tiling_matches_untiled_and_cfg4_memory(net_layers):
+    """NET.features_pair_hwc(tile_rows=...) against the untiled stack (same receptive fields; MIOpen may
+    pick another algorithm for another shape, hence a tolerance), and the peak device memory of the feature stage at
+    cfg4 (1500x1000) untiled vs tiled - the number that decides whether tiling is ever needed on a 288 GB part."""
+    import synthetic
+    from model import NET
+    net = NET(None, input_patch_size=11, batch_size=1, device="cuda").set_layers(net_layers)
+    L, R, _, _, _ = synthetic.make_pair(150, 220, 16, seed=2)
+    l, r = dev(L[:, :, 0]), dev(R[:, :, 0])
+    a = net.features_pair_hwc(l, r)
+    for rows in (37, 64, 150):
+        b = net.features_pair_hwc(l, r, tile_rows=rows)
+        err = max(float((a[0] - b[0]).abs().max()), float((a[1] - b[1]).abs().max()))
+        assert err <= 2e-6, (rows, err)
+    H, W = 1000, 1500
+    g = torch.Generator(device="cuda").manual_seed(0)
+    l, r = torch.randn((H, W), device="cuda", generator=g), torch.randn((H, W), device="cuda", generator=g)
+    peaks = {}
+    for name, rows in (("untiled", None), ("tile_rows_125", 125)):
+        net.features_pair_hwc(l, r, tile_rows=rows)              # warm-up: MIOpen picks its kernels
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        f = net.features_pair_hwc(l, r, tile_rows=rows)
+        torch.cuda.synchronize()
+        peaks[name] = int(torch.cuda.max_memory_allocated() - base)
+        del f
+    RECORD["cfg4_feature_stage_peak_bytes"] = peaks
+    _dump()
+    assert peaks["tile_rows_125"] < peaks["untiled"]
+    assert peaks["untiled"] < 16 * 2 ** 30                       # far below 288 GB: tiling stays optional
