@@ -98,6 +98,15 @@ int mccnn_cross_region_list(const mccnn_support_t *support, int H, int W, int L,
 int mccnn_cbca_iter(const float *in, float *out, const mccnn_support_t *support, int D, int H, int W, int L, int order,
                     mccnn_stream_t stream);
 
+/* The paper's support regions from BOTH views (sec. 4.1; the reference skips it, pf:122-144, 661-729 dead code).
+ * Opt-in, changes the output: at disparity d every arm used at a pixel q is min(own arm at q, the other view's arm at
+ * the partner q -/+ d) (side LEFT: x - d, RIGHT: x + d; partner outside the image: own arms).  Flat float32 running
+ * sum in the reference's order, region size counted on the way.  support_self / support_other: planes built by
+ * mccnn_cross_arms on the volume's own view and on the other view. */
+int mccnn_cbca_iter_both(const float *in, float *out, const mccnn_support_t *support_self,
+                         const mccnn_support_t *support_other, int D, int H, int W, int L, int side,
+                         mccnn_stream_t stream);
+
 /* ---- layout changes between DHW and HWD ------------------------------------------------------------------- */
 int mccnn_hwd_pitch(int D); /* Dp: D rounded up to a multiple of 4 (16-byte rows) */
 int mccnn_dhw_to_hwd(const float *dhw, float *hwd, int D, int H, int W, mccnn_stream_t stream);
@@ -135,9 +144,19 @@ int mccnn_lr_status(const float *disp_left, const float *disp_right, int H, int 
                     mccnn_stream_t stream);
 int mccnn_interpolate(const float *disp_left, const int32_t *status, int H, int W, float *out,
                       mccnn_stream_t stream);
+/* The two rules of the paper that the reference names and leaves out (pf:318, pf:361), opt-in: directions = 16 takes
+ * the median of the nearest matches along 16 rays instead of the 4 axis directions; occlusion_from_left = 1 fills an
+ * occlusion from the nearest match to its left instead of its right.  (4, 0) == mccnn_interpolate. */
+int mccnn_interpolate_ex(const float *disp_left, const int32_t *status, int H, int W, int directions,
+                         int occlusion_from_left, float *out, mccnn_stream_t stream);
 
 /* ---- a9  subpixel_enhance (pf:381-400), float32 as NumPy 2 evaluates it ------------------------------------- */
 int mccnn_subpixel(const float *disp, const float *vol_dhw, int D, int H, int W, float *out, mccnn_stream_t stream);
+/* numpy1_promotion = 1: the scalar promotion of NumPy < 2 (the reference's own Python 2.7 environment): the
+ * denominator, the quotient and the subtraction of pf:396 run in float64 and are rounded once on the store;
+ * differs from the default by <= 2.5e-5 px.  0 == mccnn_subpixel (what the golden vectors pin). */
+int mccnn_subpixel_ex(const float *disp, const float *vol_dhw, int D, int H, int W, int numpy1_promotion, float *out,
+                      mccnn_stream_t stream);
 
 /* ---- a10 median_filter (pf:403-421): clipped fh x fw window (odd sizes, fh*fw <= 49), np.median ------------- */
 int mccnn_median(const float *disp, int H, int W, int fh, int fw, float *out, mccnn_stream_t stream);

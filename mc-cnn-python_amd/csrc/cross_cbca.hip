@@ -250,6 +250,73 @@ __global__ __launch_bounds__(256) void cbca_iter_kernel(const float *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Support regions from BOTH views (MC-CNN paper, sec. 4.1; the reference leaves it out as "impractical to run" and its
+// attempt, compute_disparity_union_region pf:661-729, is dead code with a NameError).  Opt-in, changes the output.
+// For the volume of side S at disparity d, a pixel q = (y, x) has the partner q' = (y, x - d) (S = left) or (y, x + d)
+// (S = right) in the other view; every arm used at q is min(arm of S at q, arm of the other view at q'), for the
+// vertical arm of the anchor and for the horizontal arm of every pixel on it.  A pixel whose partner falls outside
+// the image keeps its own arms.  Same tile staging and the same flat float32 running sum (vertical: self, up..,
+// down..; horizontal: self, left.., right..) as the reference-order kernel; the region size is counted on the way.
+template <int R, int CB_TH>
+__global__ __launch_bounds__(256) void cbca_both_views_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                              const Support *__restrict__ sup,
+                                                              const Support *__restrict__ sup_other, int H, int W,
+                                                              int dsign)
+{
+    constexpr int IW = CB_TW + 2 * R, IH = CB_TH + 2 * R, IP = IW + 1;
+    __shared__ float tin[IH * IP];
+    const int tid = threadIdx.x;
+    const int w0 = blockIdx.x * CB_TW, h0 = blockIdx.y * CB_TH;
+    const int shift = dsign * (int)blockIdx.z;       // partner column = x + shift
+    const size_t plane = (size_t)H * W;
+    const float *src = in + (size_t)blockIdx.z * plane;
+    float *dst = out + (size_t)blockIdx.z * plane;
+    for (int i = tid; i < IH * IW; i += 256) {
+        const int r = i / IW, c = i - r * IW;
+        const int hh = h0 - R + r, ww = w0 - R + c;
+        float v = 0.f;
+        if (hh >= 0 && hh < H && ww >= 0 && ww < W) v = src[(size_t)hh * W + ww];
+        tin[r * IP + c] = v;
+    }
+    __syncthreads();
+    const int c = tid & 63;
+    const int ww = w0 + c;
+    const int xo = ww + shift;
+    const bool partner = xo >= 0 && xo < W;
+    // the four arms at (qy, ww), intersected with the partner's: {up, down, left, right}
+    auto arms = [&](int qy, int &u, int &d, int &l, int &r) {
+        const uint32_t a = sup[(size_t)qy * W + ww];
+        u = min(arm_up(a), R), d = min(arm_down(a), R), l = min(arm_left(a), R), r = min(arm_right(a), R);
+        if (partner) {
+            const uint32_t b = sup_other[(size_t)qy * W + xo];
+            u = min(u, arm_up(b)), d = min(d, arm_down(b)), l = min(l, arm_left(b)), r = min(r, arm_right(b));
+        }
+    };
+    for (int k = 0; k < CB_TH / 4; ++k) {
+        const int rr = (tid >> 6) + 4 * k;
+        const int hh = h0 + rr;
+        if (hh < H && ww < W) {
+            int nu, nd, l0, r0;
+            arms(hh, nu, nd, l0, r0);
+            float s = 0.f;
+            int n = 0;
+            const int nv = 1 + nu + nd;
+            for (int v = 0; v < nv; ++v) {
+                const int dq = v == 0 ? 0 : (v <= nu ? -v : v - nu);
+                int u, d, l, r;
+                arms(hh + dq, u, d, l, r);
+                const float *row = &tin[(rr + R + dq) * IP + c + R];
+                s += row[0];
+                for (int z = 1; z <= l; ++z) s += row[-z];
+                for (int z = 1; z <= r; ++z) s += row[z];
+                n += l + r + 1;
+            }
+            dst[(size_t)hh * W + ww] = s / (float)n;
+        }
+    }
+}
+
 template <int R, int CB_TH>
 static int launch_cbca(const float *in, float *out, const Support *sup, int D, int H, int W, int order, hipStream_t s)
 {
@@ -673,6 +740,32 @@ extern "C" int mccnn_cross_region_list(const mccnn_support_t *support, int H, in
     hipLaunchKernelGGL(cross_region_list_kernel, grid, block, 0, (hipStream_t)stream, support, H, W, (2 * L) * (2 * L),
                        region);
     return check_launch("mccnn_cross_region_list");
+}
+
+extern "C" int mccnn_cbca_iter_both(const float *in, float *out, const mccnn_support_t *support_self,
+                                    const mccnn_support_t *support_other, int D, int H, int W, int L, int side,
+                                    mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(in && out && support_self && support_other, MCCNN_E_INVALID, "mccnn_cbca_iter_both: null pointer");
+    MCCNN_REQUIRE(in != out, MCCNN_E_INVALID, "mccnn_cbca_iter_both: in-place aggregation is not defined (ping-pong)");
+    MCCNN_REQUIRE(D > 0 && H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_cbca_iter_both: non-positive size");
+    MCCNN_REQUIRE(D <= 65535, MCCNN_E_UNSUPPORTED, "mccnn_cbca_iter_both: D=%d exceeds grid.z", D);
+    MCCNN_REQUIRE(side == MCCNN_SIDE_LEFT || side == MCCNN_SIDE_RIGHT, MCCNN_E_INVALID,
+                  "mccnn_cbca_iter_both: side %d", side);
+    MCCNN_REQUIRE(L >= 1 && L <= 32, MCCNN_E_UNSUPPORTED, "mccnn_cbca_iter_both: L=%d outside [1,32]", L);
+    const int dsign = side == MCCNN_SIDE_LEFT ? -1 : 1;
+    hipStream_t s = (hipStream_t)stream;
+    if (L <= 14) {
+        const dim3 grid(cdiv(W, CB_TW), cdiv(H, 32), D);
+        hipLaunchKernelGGL((cbca_both_views_kernel<13, 32>), grid, dim3(256), 0, s, in, out, support_self, support_other,
+                           H, W, dsign);
+    } else {
+        const dim3 grid(cdiv(W, CB_TW), cdiv(H, 16), D);
+        hipLaunchKernelGGL((cbca_both_views_kernel<31, 16>), grid, dim3(256), 0, s, in, out, support_self, support_other,
+                           H, W, dsign);
+    }
+    return check_launch("mccnn_cbca_iter_both");
 }
 
 extern "C" int mccnn_cbca_iter(const float *in, float *out, const mccnn_support_t *support, int D, int H, int W, int L,

@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void lr_status_kernel(const float *__restrict_
 
 __device__ __forceinline__ float median_upto4(float *v, int n)
 {
-    // np.median of 1..4 float32 values: sort, middle element or mean of the two middle ones
+    // np.median of 1..n float32 values (n <= 4 in the reference's rule, <= 16 in the paper's): sort, middle element or
+    // mean of the two middle ones
     for (int i = 1; i < n; ++i) {
         const float x = v[i];
         int j = i - 1;
@@ -68,6 +69,56 @@ __device__ __forceinline__ float median_upto4(float *v, int n)
     }
     if (n & 1) return v[n >> 1];
     return (v[(n >> 1) - 1] + v[n >> 1]) / 2.f;
+}
+
+// The two rules the reference names but leaves out (pf:318 "in origin paper, they use 16 directions", pf:361 "they use
+// left"), as in the MC-CNN paper, sec. 4.4: a mismatch takes the median of the nearest matches along 16 rays (steps of
+// (dx, dy) in {0, +-0.5, +-1}^2 on the unit square's boundary, positions rounded half up), an occlusion takes the
+// nearest match to its LEFT.  Opt-in: they change the output.
+__constant__ float kRay16[16][2] = {{1, 0}, {1, 0.5f}, {1, 1}, {0.5f, 1}, {0, 1}, {-0.5f, 1}, {-1, 1}, {-1, 0.5f},
+                                    {-1, 0}, {-1, -0.5f}, {-1, -1}, {-0.5f, -1}, {0, -1}, {0.5f, -1}, {1, -1}, {1, -0.5f}};
+
+template <bool RAYS16, bool OCC_LEFT>
+__global__ __launch_bounds__(256) void interpolate_paper_kernel(const float *__restrict__ dl,
+                                                                const int32_t *__restrict__ st, int H, int W,
+                                                                float *__restrict__ out)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    const int h = blockIdx.y;
+    if (w >= W) return;
+    const size_t p = (size_t)h * W + w;
+    const int s = st[p];
+    float res = dl[p];
+    if (s == 1) {
+        float nb[16];
+        int c = 0;
+        if (RAYS16) {
+            for (int r = 0; r < 16; ++r) {
+                const float dx = kRay16[r][0], dy = kRay16[r][1];
+                float xx = (float)w, yy = (float)h;
+                for (;;) {
+                    xx += dx;
+                    yy += dy;
+                    const int xi = (int)floorf(xx + 0.5f), yi = (int)floorf(yy + 0.5f);
+                    if (xi < 0 || xi >= W || yi < 0 || yi >= H) break;
+                    if (st[(size_t)yi * W + xi] == 0) { nb[c++] = dl[(size_t)yi * W + xi]; break; }
+                }
+            }
+        } else {   // the reference's four axis directions, in its order (pf:321-347)
+            for (int x = w + 1; x < W; ++x) if (st[(size_t)h * W + x] == 0) { nb[c++] = dl[(size_t)h * W + x]; break; }
+            for (int x = w - 1; x >= 0; --x) if (st[(size_t)h * W + x] == 0) { nb[c++] = dl[(size_t)h * W + x]; break; }
+            for (int y = h + 1; y < H; ++y) if (st[(size_t)y * W + w] == 0) { nb[c++] = dl[(size_t)y * W + w]; break; }
+            for (int y = h - 1; y >= 0; --y) if (st[(size_t)y * W + w] == 0) { nb[c++] = dl[(size_t)y * W + w]; break; }
+        }
+        if (c > 0) res = median_upto4(nb, c);
+    } else if (s == 2) {
+        if (OCC_LEFT) {
+            for (int x = w - 1; x >= 0; --x) if (st[(size_t)h * W + x] == 0) { res = dl[(size_t)h * W + x]; break; }
+        } else {
+            for (int x = w + 1; x < W; ++x) if (st[(size_t)h * W + x] == 0) { res = dl[(size_t)h * W + x]; break; }
+        }
+    }
+    out[p] = res;
 }
 
 __global__ __launch_bounds__(256) void interpolate_kernel(const float *__restrict__ dl,
@@ -95,6 +146,12 @@ __global__ __launch_bounds__(256) void interpolate_kernel(const float *__restric
 }
 
 // ---- a9 subpixel_enhance (pf:387-396) ---------------------------------------------------------------------------
+// NUMPY1: the scalar promotion of NumPy < 2, which the reference's own Python 2.7 + NumPy 1.14 environment applies to
+// pf:396: `C_p - C_m` stays float32 (two float32 scalars), but `2. * C` pairs a float32 scalar with a Python float and
+// becomes float64, and so does everything downstream - the quotient and the subtraction run in float64 and the result
+// is rounded to float32 once, on the store.  The default is NumPy >= 2's all-float32 chain, which is what the golden
+// vectors (generated by running the reference under NumPy 2.2) pin; the two differ by <= 2.5e-5 px.
+template <bool NUMPY1>
 __global__ __launch_bounds__(256) void subpixel_kernel(const float *__restrict__ dl, const float *__restrict__ vol,
                                                        int D, long N, float *__restrict__ out)
 {
@@ -106,10 +163,17 @@ __global__ __launch_bounds__(256) void subpixel_kernel(const float *__restrict__
     if (!(im < 0 || ip >= D)) {
         const float cm = vol[(size_t)im * N + n], cp = vol[(size_t)ip * N + n], c = vol[(size_t)ic * N + n];
         const float num = cp - cm;
-        float den = cp - 2.f * c;
-        den = den + cm;
-        den = 2.f * den;
-        res = d - num / den;
+        if (NUMPY1) {
+            double den = (double)cp - 2.0 * (double)c;
+            den = den + (double)cm;
+            den = 2.0 * den;
+            res = (float)((double)d - (double)num / den);
+        } else {
+            float den = cp - 2.f * c;
+            den = den + cm;
+            den = 2.f * den;
+            res = d - num / den;
+        }
     }
     out[n] = res;
 }
@@ -357,6 +421,44 @@ extern "C" int mccnn_interpolate(const float *disp_left, const int32_t *status, 
     return check_launch("mccnn_interpolate");
 }
 
+extern "C" int mccnn_interpolate_ex(const float *disp_left, const int32_t *status, int H, int W, int directions,
+                                    int occlusion_from_left, float *out, mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(disp_left && status && out, MCCNN_E_INVALID, "mccnn_interpolate_ex: null pointer");
+    MCCNN_REQUIRE(H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_interpolate_ex: non-positive size");
+    MCCNN_REQUIRE(disp_left != out, MCCNN_E_INVALID, "mccnn_interpolate_ex: out must not alias the input map");
+    MCCNN_REQUIRE(directions == 4 || directions == 16, MCCNN_E_INVALID, "mccnn_interpolate_ex: directions=%d (4 or 16)",
+                  directions);
+    const dim3 grid(cdiv(W, 256), H), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (directions == 16 && occlusion_from_left)
+        hipLaunchKernelGGL((interpolate_paper_kernel<true, true>), grid, block, 0, s, disp_left, status, H, W, out);
+    else if (directions == 16)
+        hipLaunchKernelGGL((interpolate_paper_kernel<true, false>), grid, block, 0, s, disp_left, status, H, W, out);
+    else if (occlusion_from_left)
+        hipLaunchKernelGGL((interpolate_paper_kernel<false, true>), grid, block, 0, s, disp_left, status, H, W, out);
+    else
+        hipLaunchKernelGGL(interpolate_kernel, grid, block, 0, s, disp_left, status, H, W, out);
+    return check_launch("mccnn_interpolate_ex");
+}
+
+extern "C" int mccnn_subpixel_ex(const float *disp, const float *vol_dhw, int D, int H, int W, int numpy1_promotion,
+                                 float *out, mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(disp && vol_dhw && out, MCCNN_E_INVALID, "mccnn_subpixel_ex: null pointer");
+    MCCNN_REQUIRE(D > 0 && H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_subpixel_ex: non-positive size");
+    const long N = (long)H * W;
+    if (numpy1_promotion)
+        hipLaunchKernelGGL(subpixel_kernel<true>, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, disp, vol_dhw, D,
+                           N, out);
+    else
+        hipLaunchKernelGGL(subpixel_kernel<false>, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, disp, vol_dhw,
+                           D, N, out);
+    return check_launch("mccnn_subpixel_ex");
+}
+
 extern "C" int mccnn_subpixel(const float *disp, const float *vol_dhw, int D, int H, int W, float *out,
                               mccnn_stream_t stream)
 {
@@ -364,7 +466,7 @@ extern "C" int mccnn_subpixel(const float *disp, const float *vol_dhw, int D, in
     MCCNN_REQUIRE(disp && vol_dhw && out, MCCNN_E_INVALID, "mccnn_subpixel: null pointer");
     MCCNN_REQUIRE(D > 0 && H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_subpixel: non-positive size");
     const long N = (long)H * W;
-    hipLaunchKernelGGL(subpixel_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, disp, vol_dhw, D, N,
+    hipLaunchKernelGGL(subpixel_kernel<false>, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, disp, vol_dhw, D, N,
                        out);
     return check_launch("mccnn_subpixel");
 }

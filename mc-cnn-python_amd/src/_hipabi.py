@@ -36,6 +36,7 @@ SIGNATURES = {
     "mccnn_cross_arms": (_i, [_vp, _i, _i, _f, _i, _vp, _vp]),
     "mccnn_cross_region_list": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mccnn_cbca_iter": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mccnn_cbca_iter_both": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mccnn_hwd_pitch": (_i, [_i]),
     "mccnn_dhw_to_hwd": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "mccnn_hwd_to_dhw": (_i, [_vp, _vp, _i, _i, _i, _vp]),
@@ -47,7 +48,9 @@ SIGNATURES = {
     "mccnn_wta": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mccnn_lr_status": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "mccnn_interpolate": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "mccnn_interpolate_ex": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "mccnn_subpixel": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "mccnn_subpixel_ex": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "mccnn_median": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mccnn_bilateral": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _vp, _vp]),
     "mccnn_bias_act": (_i, [_vp, _vp, _i, _i, ctypes.c_long, _i, _vp]),

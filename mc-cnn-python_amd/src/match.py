@@ -61,6 +61,16 @@ parser.add_argument("--fast", action="store_true",
                          "<= 2e-6; CBCA through float64 prefix sums, <= 1e-6 per iteration) - about 10x faster.  "
                          "Without it every stage after the conv features is bit-identical to the reference's NumPy code")
 parser.add_argument("--exact", action="store_true", help="(default; kept for compatibility) the bit-exact variants")
+# opt-in departures from the reference's results: what the MC-CNN paper does and the reference names but leaves out
+parser.add_argument("--paper_support_regions", action="store_true",
+                    help="CBCA support regions intersected with the other view's at every disparity (paper sec. 4.1; "
+                         "the reference skips this as impractical, process_functional.py:122-144)")
+parser.add_argument("--paper_interpolation", action="store_true",
+                    help="fill mismatches from 16 rays and occlusions from the left (paper sec. 4.4; "
+                         "process_functional.py:318, :361 note the reference uses 4 directions and the right)")
+parser.add_argument("--numpy1_promotion", action="store_true",
+                    help="evaluate the sub-pixel formula as NumPy < 2 promotes its scalars (float64, rounded once), "
+                         "i.e. as the reference's own Python 2.7 environment does; differs by <= 2.5e-5 px")
 
 # different file names
 left_image_suffix = "im0.png"
@@ -122,7 +132,10 @@ def main(argv=None):
     matcher = sd.StereoMatcher(
         net, hyper_parameters(args),
         cv_mode=hip.MCCNN_CV_MFMA if args.fast else hip.MCCNN_CV_EXACT,
-        cbca_order=hip.MCCNN_CBCA_SEPARABLE if args.fast else hip.MCCNN_CBCA_REFERENCE_ORDER)
+        cbca_order=hip.MCCNN_CBCA_SEPARABLE if args.fast else hip.MCCNN_CBCA_REFERENCE_ORDER,
+        extras=dict(both_view_support=args.paper_support_regions,
+                    interpolation_directions=16 if args.paper_interpolation else 4,
+                    occlusion_from_left=args.paper_interpolation, numpy1_promotion=args.numpy1_promotion))
 
     for index in shard_indices(args.start, args.end, len(left_paths), rank, world):
         left_path = left_paths[index]

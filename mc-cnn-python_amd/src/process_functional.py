@@ -13,6 +13,14 @@ Options the reference does not have (module attributes; the DEFAULTS are the bit
 user gets the reference's numbers - the fast ones are opt-in and only tolerance-bounded):
     COST_VOLUME_MODE  "exact" (NumPy summation order, bit-exact, default) | "mfma" (matrix cores, <= 2e-6 abs)
     CBCA_ORDER        "reference" (flat list order, bit-exact, default) | "separable" (fast, <= 1e-6 abs per iteration)
+Opt-in departures from the reference's results (defaults reproduce it):
+    CBCA_BOTH_VIEWS          False | True  - the paper's support regions intersected with the other view's (pf:122-144
+                                             names it and skips it as impractical; pf:661-729 is its dead attempt)
+    INTERPOLATION_DIRECTIONS 4 | 16        - mismatches filled from 16 rays as in the paper (pf:318)
+    OCCLUSION_FROM_LEFT      False | True  - occlusions filled from the nearest match on the left, as in the paper (pf:361)
+    NUMPY1_PROMOTION         False | True  - sub-pixel formula evaluated as NumPy < 2 promotes its scalars (float64,
+                                             rounded once): what the reference's own Python 2.7 + NumPy 1.14 computes;
+                                             the default is NumPy >= 2's float32 chain, which the golden vectors pin
 """
 import numpy as np
 import torch
@@ -23,6 +31,10 @@ from model import NET
 
 COST_VOLUME_MODE = "exact"
 CBCA_ORDER = "reference"
+CBCA_BOTH_VIEWS = False
+INTERPOLATION_DIRECTIONS = 4
+OCCLUSION_FROM_LEFT = False
+NUMPY1_PROMOTION = False
 
 _CV_MODES = {"exact": hip.MCCNN_CV_EXACT, "mfma": hip.MCCNN_CV_MFMA}
 _CBCA_ORDERS = {"separable": hip.MCCNN_CBCA_SEPARABLE, "reference": hip.MCCNN_CBCA_REFERENCE_ORDER}
@@ -99,14 +111,18 @@ def cost_volume_aggregation(left_image, right_image, left_cost_volume, right_cos
     """pf:117-183.  Inputs are not modified; fresh volumes are returned."""
     outs = []
     was_np = False
-    for image, vol in ((left_image, left_cost_volume), (right_image, right_cost_volume)):
-        img, _ = _img(image)
+    images = [_img(left_image)[0], _img(right_image)[0]]
+    supports = [sd.cross_arms(img, intensity_threshold, int(distance_threshold)) for img in images]
+    for k, vol in enumerate((left_cost_volume, right_cost_volume)):
         v, was_np = _dev(vol)
         if torch.is_tensor(vol) and v.data_ptr() == vol.data_ptr():
             v = v.clone()  # the ping-pong clobbers its input; the reference leaves the caller's array alone
-        support = sd.cross_arms(img, intensity_threshold, int(distance_threshold))
-        res, _spare = sd.cbca(v, torch.empty_like(v), support, int(max_average_time), int(distance_threshold),
-                              _CBCA_ORDERS[CBCA_ORDER])
+        if CBCA_BOTH_VIEWS:
+            res, _spare = sd.cbca_both_views(v, torch.empty_like(v), supports[k], supports[1 - k], int(max_average_time),
+                                             int(distance_threshold), hip.MCCNN_SIDE_LEFT if k == 0 else hip.MCCNN_SIDE_RIGHT)
+        else:
+            res, _spare = sd.cbca(v, torch.empty_like(v), supports[k], int(max_average_time), int(distance_threshold),
+                                  _CBCA_ORDERS[CBCA_ORDER])
         outs.append(_ret(res, was_np))
     return outs[0], outs[1]
 
@@ -171,14 +187,15 @@ def interpolation(left_disparity_map, right_disparity_map, ndisp):
     dl, was_np = _dev(left_disparity_map)
     dr, _ = _dev(right_disparity_map)
     st = sd.lr_status(dl, dr, int(ndisp))
-    return _ret(sd.interpolate(dl, st), was_np)
+    return _ret(sd.interpolate(dl, st, directions=INTERPOLATION_DIRECTIONS, occlusion_from_left=OCCLUSION_FROM_LEFT),
+                was_np)
 
 
 def subpixel_enhance(left_disparity_map, left_cost_volume):
     """pf:381-400."""
     dl, was_np = _dev(left_disparity_map)
     v, _ = _dev(left_cost_volume)
-    return _ret(sd.subpixel(dl, v), was_np)
+    return _ret(sd.subpixel(dl, v, numpy1_promotion=NUMPY1_PROMOTION), was_np)
 
 
 def median_filter(left_disparity_map, filter_height, filter_width):

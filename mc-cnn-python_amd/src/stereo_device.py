@@ -159,6 +159,23 @@ def cbca(vol, tmp, support, iterations, distance_threshold, order=hip.MCCNN_CBCA
     return src, dst
 
 
+def cbca_both_views(vol, tmp, support_self, support_other, iterations, distance_threshold, side, timer=None):
+    """`iterations` rounds of cross-based averaging with the paper's two-view support regions (opt-in extra, see
+    mccnn_cbca_iter_both): arms intersected with the other view's at the partner pixel x -/+ d.  Same ping-pong
+    contract as cbca()."""
+    D, H, W = vol.shape
+    lib = hip.load()
+    src, dst = vol, tmp
+    timer = timer or _NO_TIMER
+    for _ in range(int(iterations)):
+        timer.start("cbca_iter_both")
+        hip.check(lib.mccnn_cbca_iter_both(hip.ptr(src), hip.ptr(dst), hip.ptr(support_self), hip.ptr(support_other), D, H,
+                                           W, int(distance_threshold), int(side), hip.stream()), "mccnn_cbca_iter_both")
+        timer.stop()
+        src, dst = dst, src
+    return src, dst
+
+
 # ---- a5 / a6 -------------------------------------------------------------------------------------------------------
 def hwd_pitch(D):
     return hip.load().mccnn_hwd_pitch(int(D))
@@ -266,19 +283,30 @@ def lr_status(dl, dr, ndisp, out=None):
     return st
 
 
-def interpolate(dl, status, out=None):
+def interpolate(dl, status, out=None, directions=4, occlusion_from_left=False):
+    """directions / occlusion_from_left: the paper's rules the reference leaves out (pf:318, pf:361), opt-in."""
     H, W = dl.shape
     out = out if out is not None else torch.empty_like(dl)
-    hip.check(hip.load().mccnn_interpolate(hip.ptr(dl), hip.ptr(status), H, W, hip.ptr(out), hip.stream()),
-              "mccnn_interpolate")
+    if int(directions) == 4 and not occlusion_from_left:
+        hip.check(hip.load().mccnn_interpolate(hip.ptr(dl), hip.ptr(status), H, W, hip.ptr(out), hip.stream()),
+                  "mccnn_interpolate")
+    else:
+        hip.check(hip.load().mccnn_interpolate_ex(hip.ptr(dl), hip.ptr(status), H, W, int(directions),
+                                                  1 if occlusion_from_left else 0, hip.ptr(out), hip.stream()),
+                  "mccnn_interpolate_ex")
     return out
 
 
-def subpixel(dl, vol, out=None):
+def subpixel(dl, vol, out=None, numpy1_promotion=False):
+    """numpy1_promotion: evaluate pf:396 as NumPy < 2 promotes it (float64, rounded once) instead of in float32."""
     D, H, W = vol.shape
     out = out if out is not None else torch.empty_like(dl)
-    hip.check(hip.load().mccnn_subpixel(hip.ptr(dl), hip.ptr(vol), D, H, W, hip.ptr(out), hip.stream()),
-              "mccnn_subpixel")
+    if numpy1_promotion:
+        hip.check(hip.load().mccnn_subpixel_ex(hip.ptr(dl), hip.ptr(vol), D, H, W, 1, hip.ptr(out), hip.stream()),
+                  "mccnn_subpixel_ex")
+    else:
+        hip.check(hip.load().mccnn_subpixel(hip.ptr(dl), hip.ptr(vol), D, H, W, hip.ptr(out), hip.stream()),
+                  "mccnn_subpixel")
     return out
 
 
@@ -339,7 +367,7 @@ class StereoMatcher(object):
     """
 
     def __init__(self, net, hp=None, cv_mode=hip.MCCNN_CV_EXACT, cbca_order=hip.MCCNN_CBCA_SEPARABLE,
-                 feature_tile_rows=None):
+                 feature_tile_rows=None, extras=None):
         self.device = hip.require_device()
         self.net = net
         self.hp = dict(DEFAULT_HP)
@@ -348,6 +376,15 @@ class StereoMatcher(object):
         self.cv_mode = cv_mode
         self.cbca_order = cbca_order
         self.feature_tile_rows = feature_tile_rows   # None: whole image; else NET.features_pair_hwc's band height
+        # opt-in departures from the reference (they change the output): the paper's rules it leaves out, and the
+        # scalar promotion of the NumPy it was written for
+        self.extras = dict(both_view_support=False, interpolation_directions=4, occlusion_from_left=False,
+                           numpy1_promotion=False)
+        if extras:
+            unknown = set(extras) - set(self.extras)
+            if unknown:
+                raise ValueError("unknown extras: %s" % sorted(unknown))
+            self.extras.update(extras)
         self._ws = {}
         self._graphs = {}
 
@@ -402,11 +439,16 @@ class StereoMatcher(object):
         sup_r = cross_arms(R, hp["cbca_intensity"], hp["cbca_distance"], out=ws["sup_r"])
         timer.stop()
 
+        ex = self.extras
+
+        def aggregate(vol, tmp, own, other, n, side):
+            if ex["both_view_support"]:
+                return cbca_both_views(vol, tmp, own, other, n, hp["cbca_distance"], side, timer)
+            return cbca(vol, tmp, own, n, hp["cbca_distance"], self.cbca_order, timer)
+
         t1d, t2d = ws["t1"][:nd].view(dhw), ws["t2"][:nd].view(dhw)
-        lcv, t1d = cbca(lcv, t1d, sup_l, hp["cbca_num_iterations1"], hp["cbca_distance"], self.cbca_order,
-                        timer)
-        rcv, t2d = cbca(rcv, t2d, sup_r, hp["cbca_num_iterations1"], hp["cbca_distance"], self.cbca_order,
-                        timer)
+        lcv, t1d = aggregate(lcv, t1d, sup_l, sup_r, hp["cbca_num_iterations1"], hip.MCCNN_SIDE_LEFT)
+        rcv, t2d = aggregate(rcv, t2d, sup_r, sup_l, hp["cbca_num_iterations1"], hip.MCCNN_SIDE_RIGHT)
         if keep is not None:
             keep["cbca1"] = (lcv.clone(), rcv.clone())
 
@@ -421,10 +463,8 @@ class StereoMatcher(object):
         if keep is not None:
             keep["sgm"] = (lcv.clone(), rcv.clone())
 
-        lcv, t1d = cbca(lcv, t1d, sup_l, hp["cbca_num_iterations2"], hp["cbca_distance"], self.cbca_order,
-                        timer)
-        rcv, t2d = cbca(rcv, t2d, sup_r, hp["cbca_num_iterations2"], hp["cbca_distance"], self.cbca_order,
-                        timer)
+        lcv, t1d = aggregate(lcv, t1d, sup_l, sup_r, hp["cbca_num_iterations2"], hip.MCCNN_SIDE_LEFT)
+        rcv, t2d = aggregate(rcv, t2d, sup_r, sup_l, hp["cbca_num_iterations2"], hip.MCCNN_SIDE_RIGHT)
         if keep is not None:
             keep["cbca2"] = (lcv.clone(), rcv.clone())
 
@@ -437,8 +477,9 @@ class StereoMatcher(object):
         timer.stop()
         timer.start("post")
         st = lr_status(dl, dr, D, out=ws["status"] if keep is None else None)
-        di = interpolate(dl, st, out=m[2])
-        ds = subpixel(di, lcv, out=m[3])
+        di = interpolate(dl, st, out=m[2], directions=ex["interpolation_directions"],
+                         occlusion_from_left=ex["occlusion_from_left"])
+        ds = subpixel(di, lcv, out=m[3], numpy1_promotion=ex["numpy1_promotion"])
         dm = median(ds, 5, 5, out=m[4])
         db = bilateral(L, dm, 5, 5, 0, hp["blur_sigma"], hp["blur_threshold"], out=m[5])
         timer.stop()
