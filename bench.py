@@ -167,8 +167,16 @@ def main():
         cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER if args.exact else hip.MCCNN_CBCA_SEPARABLE)
 
     use_graph = not args.no_graph
+    if use_graph:
+        try:                                     # the first call warms up eagerly, then captures
+            matcher.match_graph(dl, dr, D)
+            torch.cuda.synchronize()
+        except Exception as e:                   # capture refused (e.g. a library call that cannot be captured):
+            sys.stderr.write("bench: hipGraph capture failed (%s); launching kernel by kernel\n" % e)   # still the HIP path
+            use_graph = False
+            torch.cuda.synchronize()
     run = (lambda: matcher.match_graph(dl, dr, D)) if use_graph else (lambda: matcher.match(dl, dr, D))
-    for _ in range(max(args.warmup, 1 if use_graph else 0)):      # the first graph call captures
+    for _ in range(args.warmup):
         run()
     torch.cuda.synchronize()
     mgpu.barrier()
