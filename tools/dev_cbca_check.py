@@ -30,16 +30,14 @@ for (H, W, D) in shapes:
         torch.cuda.synchronize()
         assert float(guard[:32].min()) == 777.0 and float(guard[-32:].min()) == 777.0, "out-of-bounds store"
         outs[order] = dst.clone()
-    d02 = float((outs[0] - outs[2]).abs().max()) if 2 in outs else float('nan')
     d01 = float((outs[0] - outs[1]).abs().max())
-    d21 = float((outs[2] - outs[1]).abs().max()) if 2 in outs else float('nan')
     # several iterations, ping-pong
     a, _ = sd.cbca(v.clone(), torch.empty_like(v), sup, 5, 14, 0)
     b, _ = sd.cbca(v.clone(), torch.empty_like(v), sup, 5, 14, 1)
     d5 = float((a - b).abs().max())
     ok = d01 <= 1e-6 and d5 <= 2e-6 and bool(torch.isfinite(outs[0]).all())
     bad += 0 if ok else 1
-    print("%4dx%4dx%2d  new-old %.2e  new-ref %.2e  old-ref %.2e  5 iters new-ref %.2e  maxcount %d  %s"
-          % (H, W, D, d02, d01, d21, d5, int(sd.support_count(sup).max()), "ok" if ok else "FAIL"), flush=True)
+    print("%4dx%4dx%2d  streaming vs reference order: 1 iteration %.2e, 5 iterations %.2e  (largest region %d)  %s"
+          % (H, W, D, d01, d5, int(sd.support_count(sup).max()), "ok" if ok else "FAIL"), flush=True)
 print("FAILED %d" % bad if bad else "ALL OK")
 sys.exit(1 if bad else 0)
