@@ -13,6 +13,13 @@ Differences a maintainer should know:
   * whole-image features use the HIP epilogue mccnn_l2norm_chw_to_hwc (NCHW conv output -> NHWC unit vectors).
 """
 import math
+import os
+
+# MIOpen times every applicable solver the first time it meets a convolution shape; its reference "naive" direct
+# convolutions take ~150 ms per call at image size and never win - leaving them out of the search saves ~6 s per
+# process (forward) and more with the backward passes of training.  The user's own setting, if any, is kept.
+for _v in ("FWD", "BWD", "WRW"):
+    os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + _v, "0")
 
 import numpy as np
 import torch
