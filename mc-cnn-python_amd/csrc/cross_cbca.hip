@@ -81,20 +81,30 @@ __global__ __launch_bounds__(256) void cross_arms_kernel(const float *__restrict
 // its column alone, so the address arithmetic is done once per image instead of once per pixel per plane per iteration.
 namespace s4 {
 constexpr int R = 13;             // longest arm the kernel serves (distance threshold L <= 14)
-constexpr int CPL = 4;            // columns per lane
-constexpr int CS = 64 * CPL;      // staged columns per strip (one 16-byte load per lane per row)
-constexpr int HL = 16;            // staged columns left of the first output column (>= R + 1, multiple of CPL)
-constexpr int OUTW = 224;         // output columns per strip: HL + OUTW - 1 + R <= CS - 1; 7 x 128 bytes per row
-constexpr int B = 4;              // rows per pipeline batch
+constexpr int CPL = 4;            // OUTPUT columns per lane (hsum / emit stages, 16-byte stores)
+constexpr int CPS = 5;            // STAGED columns per lane of the scan stage (one 16-byte + one 4-byte load per row)
+constexpr int CS = 64 * CPS;      // staged columns per strip
+constexpr int HL = 15;            // staged columns left of the first output column (>= R + 1, multiple of CPS so that
+                                  // a scan lane lies entirely inside or entirely outside the image at its left edge)
+constexpr int OUTW = 64 * CPL;    // 256 output columns per strip: every lane of the hsum / emit waves is used, and
+                                  // a 750-wide image is 3 strips (with 4 columns per scan lane and 224 outputs it was 4)
+#ifndef CBCA_B
+#define CBCA_B 3
+#endif
+constexpr int B = CBCA_B;         // rows per pipeline batch (the kernel runs at its LDS / vector-memory throughput: 2, 3
+                                  // or 4 rows per barrier measure the same; 3 is what the double-buffered prow leaves
+                                  // room for beside the rings of two planes in 160 KiB)
 constexpr int RING = 32;          // rows of the column-prefix ring (power of two: the wrap is a bit mask)
 constexpr int SUBB = 64 * 8;      // one column-phase sub-array: 64 lanes x 8 bytes
-constexpr int ROWB = CPL * SUBB;  // bytes of one staged row of float64 prefix sums (prow) / one ring row
-static_assert(HL >= R + 1 && HL % CPL == 0 && HL + OUTW + R <= CS && OUTW % CPL == 0, "strip geometry");
+constexpr int ROWB = CPL * SUBB;  // bytes of one ring row (float64 column prefixes of the 256 outputs)
+constexpr int PROWB = CPS * SUBB; // bytes of one prow row (float64 row prefixes of the 320 staged columns)
+static_assert(HL >= R + 1 && HL % CPS == 0 && HL + OUTW + R <= CS, "strip geometry");
 static_assert(ROWB == 2048 && RING * ROWB == 65536, "the emit stage's address math assumes 2 KiB rows, 32 of them");
-// Column-phase layout of a row of 256 float64: entry i lives in sub-array i % 4 at slot i / 4, so the four values a
-// lane owns go out as four conflict-free 8-byte stores (lane stride 8 B) and gathers of neighbouring lanes that use
-// equal arms hit distinct banks.
-__host__ __device__ constexpr uint32_t elem(int i) { return (uint32_t)((i & 3) * SUBB + (i >> 2) * 8); }
+static_assert(RING >= B + 2 * R + 1, "ring must hold the emit window plus the batch being written");
+// Column-phase layout of a prow row: staged entry i lives in sub-array i % 5 at slot i / 5 (the scan lane that owns
+// it), so the five values a lane owns go out as conflict-free 8-byte stores (lane stride 8 B) and gathers of
+// neighbouring lanes that use equal arms hit distinct banks.  Ring rows use the same scheme with 4 phases.
+__host__ __device__ constexpr uint32_t elem(int i) { return (uint32_t)((i % CPS) * SUBB + (i / CPS) * 8); }
 }  // namespace s4
 
 // Support buffer: plane 0 [H][W] uint32 (arms + size, documented in mccnn.h), then - each 16-byte aligned -
@@ -343,8 +353,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------------------------------
 // cbca_stream_kernel: the separable aggregation (MCCNN_CBCA_SEPARABLE, L <= 14), O(1) work per output.
 //
-// A strip of 256 staged columns (224 outputs) of one disparity plane is streamed down its rows:
-//   row y arrives (4 floats per lane)
+// A strip of 256 output columns (284 staged: 15 + 13 halo columns) of one disparity plane is streamed down its rows:
+//   row y arrives (5 floats per lane of the scan wave)
 //     -> float64 inclusive prefix sum P along the row (lane-local prefix + DPP scan across the 64 lanes)   [scan]
 //     -> horizontal-arm sum of pixel (y,c) = P[i+right] - P[i-left-1]; running float64 column prefix
 //        Q[y][c] += that, kept in a 32-row LDS ring                                                        [hsum]
@@ -358,13 +368,15 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 //     a vertical lookup is v_lshl_add + v_and_or (the 32-row ring wraps by mask), the reciprocal is used as stored;
 //   * prow and the ring use the column-phase layout (s4::elem): stores and the ring gathers are conflict-free by
 //     construction, prow gathers are conflict-free wherever neighbouring lanes use equal arms;
-//   * 16-byte loads / stores per lane, halo columns 12.5 % of a strip, the 64-lane scan paid once per 256 columns.
-// Pipeline: waves are specialised by stage and run in lock step, one s_barrier per batch of B = 4 rows:
+//   * 16-byte stores and 16+4-byte loads per lane, halo columns 10 % of a strip, all 64 lanes of the hsum / emit waves
+//     busy, the 64-lane scan paid once per 256 outputs; 750 columns are 3 strips.
+// Pipeline: waves are specialised by stage and run in lock step, one s_barrier per batch of B = 3 rows:
 //     iteration t:  scan  batch t    -> prow[t & 1]
-//                   hsum  batch t-1  -> ring rows 4(t-1) .. 4(t-1)+3
+//                   hsum  batch t-1  -> ring rows B(t-1) .. B(t-1)+B-1
 //                   emit  batch t-2  :  "above" lookups Q[y+down] now; the "below" lookups Q[y-up-1] were fetched one
 //                                       iteration earlier (rows <= y-1 are long complete) - with that the 27-row
 //                                       window plus the rows being written fit the 32-row ring.
+// scan x3 (one row each), hsum x1, emit x3 (one row each): seven waves per plane.
 // A workgroup runs PPW = 2 such pipelines (two planes of the same strip) behind the same barriers: the second one's
 // support words are the cache lines the first one just brought into L1 (TCP->L2 read requests -35 %).
 // Edges: nothing is clamped along a row.  Lanes whose columns fall outside the image read whatever the buffer range
@@ -372,8 +384,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // cancel in the prefix differences.  Rows past the bottom re-read the last row (never referenced).  Stores outside the
 // image / chunk are dropped by an out-of-range offset.
 #ifndef CBCA_NSCAN
-#define CBCA_NSCAN 1   // scan waves per pipeline (rows of a batch split between them)
-#define CBCA_NEMIT 2   // emit waves per pipeline (rows split)
+#define CBCA_NSCAN 3   // scan waves per pipeline (rows of a batch split between them: one row each)
+#define CBCA_NEMIT 3   // emit waves per pipeline (rows split: one row each)
 #endif
 #ifndef CBCA_NHS
 #define CBCA_NHS 1     // hsum waves per pipeline (each owns CPL / NHS of a lane's four columns)
@@ -402,9 +414,9 @@ __global__ __launch_bounds__(64 * PPW * (NSCAN + NHS + NEMIT)) void cbca_stream_
     using namespace s4;
     constexpr int NPF = 4;                      // batches of loads every wave keeps in flight
     constexpr int SR = B / NSCAN, ER = B / NEMIT;
-    constexpr int PROW_BYTES = 2 * B * ROWB;    // double-buffered by batch parity
+    constexpr int PROW_BYTES = 2 * B * PROWB;   // double-buffered by batch parity
     constexpr int NW = NSCAN + NHS + NEMIT;     // waves of one pipeline
-    __shared__ double lds[PPW * (PROW_BYTES + RING * ROWB) / 8];   // 80 KiB per pipeline
+    __shared__ double lds[PPW * (PROW_BYTES + RING * ROWB) / 8];   // 79 KiB per pipeline
     const int lane = threadIdx.x & 63;
     const int wave_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // waves w and w + 4 of a workgroup share a SIMD: the second pipeline takes its roles in rotated order so that a
@@ -439,21 +451,27 @@ __global__ __launch_bounds__(64 * PPW * (NSCAN + NHS + NEMIT)) void cbca_stream_
         const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(in + (size_t)d * plane), 0, (int)(plane * 4), 0x00020000);
         const int b0 = wave * SR;
-        const int vb = 4 * max(w0 - HL + CPL * lane, 0);
+        const int x0 = w0 - HL + CPS * lane;     // image column of this lane's first staged entry
+        const int vb = 4 * (x0 + CPS <= 0 ? 0 : x0);   // lanes entirely left of the image read (and never publish) column 0..
         u32x4 vv[NPF][SR];
+        uint32_t v5[NPF][SR];
         auto issue = [&](int slot, int k) {
 #pragma unroll
-            for (int j = 0; j < SR; ++j)
-                vv[slot][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, vb, min(ys + k * B + b0 + j, ye) * rowv, 0);
+            for (int j = 0; j < SR; ++j) {
+                const int so = min(ys + k * B + b0 + j, ye) * rowv;
+                vv[slot][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, vb, so, 0);
+                v5[slot][j] = __builtin_amdgcn_raw_buffer_load_b32(rs_src, vb + 16, so, 0);
+            }
         };
         auto scan_batch = [&](int slot, int par, int t) {
-            double p0[SR], p1[SR], p2[SR], tt[SR], ex[SR];
+            double p0[SR], p1[SR], p2[SR], p3[SR], tt[SR], ex[SR];
 #pragma unroll
             for (int j = 0; j < SR; ++j) {
                 p0[j] = (double)__uint_as_float(vv[slot][j].x);
                 p1[j] = p0[j] + (double)__uint_as_float(vv[slot][j].y);
                 p2[j] = p1[j] + (double)__uint_as_float(vv[slot][j].z);
-                tt[j] = p2[j] + (double)__uint_as_float(vv[slot][j].w);
+                p3[j] = p2[j] + (double)__uint_as_float(vv[slot][j].w);
+                tt[j] = p3[j] + (double)__uint_as_float(v5[slot][j]);
             }
             // steps outermost so the rows' dependent chains interleave (a lone chain issues one VALU per ~5 cycles)
 #pragma unroll
@@ -472,11 +490,12 @@ __global__ __launch_bounds__(64 * PPW * (NSCAN + NHS + NEMIT)) void cbca_stream_
             for (int j = 0; j < SR; ++j) ex[j] = dpp_f64<0x138>(tt[j]);         // wave_shr:1 -> exclusive
 #pragma unroll
             for (int j = 0; j < SR; ++j) {
-                char *pr = ldsb + (par * B + b0 + j) * ROWB + lane8;
+                char *pr = ldsb + (par * B + b0 + j) * PROWB + lane8;
                 *reinterpret_cast<double *>(pr + 0 * SUBB) = ex[j] + p0[j];
                 *reinterpret_cast<double *>(pr + 1 * SUBB) = ex[j] + p1[j];
                 *reinterpret_cast<double *>(pr + 2 * SUBB) = ex[j] + p2[j];
-                *reinterpret_cast<double *>(pr + 3 * SUBB) = tt[j];
+                *reinterpret_cast<double *>(pr + 3 * SUBB) = ex[j] + p3[j];
+                *reinterpret_cast<double *>(pr + 4 * SUBB) = tt[j];
             }
             issue(slot, t + NPF);
         };
@@ -521,14 +540,14 @@ __global__ __launch_bounds__(64 * PPW * (NSCAN + NHS + NEMIT)) void cbca_stream_
             double hs[B][CH];
             {
                 double pa[B][CH], pb[B][CH];     // all prow reads in flight before the first use
-                const char *prb = ldsb + par * (B * ROWB);
+                const char *prb = ldsb + par * (B * PROWB);
 #pragma unroll
                 for (int b = 0; b < B; ++b)
 #pragma unroll
                     for (int j = 0; j < CH; ++j) {
                         const uint32_t wd = sy[slot][b][j];
-                        pa[b][j] = *reinterpret_cast<const double *>(prb + b * ROWB + (wd & 0xffffu));
-                        pb[b][j] = *reinterpret_cast<const double *>(prb + b * ROWB + (wd >> 16));
+                        pa[b][j] = *reinterpret_cast<const double *>(prb + b * PROWB + (wd & 0xffffu));
+                        pb[b][j] = *reinterpret_cast<const double *>(prb + b * PROWB + (wd >> 16));
                     }
 #pragma unroll
                 for (int b = 0; b < B; ++b)
@@ -574,7 +593,7 @@ __global__ __launch_bounds__(64 * PPW * (NSCAN + NHS + NEMIT)) void cbca_stream_
         const int b0 = (wave - NSCAN - NHS) * ER;
         const int c0 = w0 + CPL * lane;
         constexpr int kDrop = 0x7ffffff0;        // byte offset past every plane: the range check drops the store
-        const int nval = lane < OUTW / CPL ? min(max(W - c0, 0), CPL) : 0;   // valid output columns of this lane
+        const int nval = min(max(W - c0, 0), CPL);   // valid output columns of this lane
         const int ob = 4 * c0;
         const int obf = nval == CPL ? ob : kDrop;
         const bool ragged = __builtin_amdgcn_readfirstlane((W & (CPL - 1)) != 0 && w0 + OUTW > W);
