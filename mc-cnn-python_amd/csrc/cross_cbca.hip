@@ -409,7 +409,7 @@ __device__ __forceinline__ void pipe_sync()
 template <int NSCAN, int NEMIT>
 __global__ __launch_bounds__(64 * PPW * (NSCAN + NHS + NEMIT)) void cbca_stream_kernel(
     const float *__restrict__ in, float *__restrict__ out, const Support *__restrict__ sup, int D, int H, int W,
-    int rows, int nstrips, int nchunks, int total)
+    int rows, int nstrips, int nchunks, int total, int nfull)
 {
     using namespace s4;
     constexpr int NPF = 4;                      // batches of loads every wave keeps in flight
@@ -423,16 +423,28 @@ __global__ __launch_bounds__(64 * PPW * (NSCAN + NHS + NEMIT)) void cbca_stream_
     // pipeline's longest instruction stream (scan) is not paired with its twin
     const int pipe = wave_wg / NW, wave = (wave_wg % NW + pipe * (NW / 2)) % NW;
     char *const ldsb = reinterpret_cast<char *>(lds) + pipe * (PROW_BYTES + RING * ROWB);
-    int id;
-    {   // XCD-aware order: neighbouring strips of one plane (shared halo columns, shared support rows) on one L2
-        const int b = blockIdx.x, q = total >> 3, r = total & 7, x = b & 7;
-        id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    // Work items.  The first `nfull` workgroups (a multiple of 8, dispatched first) each take one (strip, plane group) at
+    // full height; the remaining ones take the remaining (strip, plane group) pairs cut into `nchunks` row chunks of
+    // `rows` rows (each re-stages 2R halo rows).  Inside either group the order is XCD-aware: the dispatcher deals
+    // consecutive workgroups to the 8 XCDs round-robin, and every XCD gets a contiguous range of items, so that
+    // neighbouring strips of one plane (shared halo columns, shared support rows) meet in one L2.
+    auto xcd_order = [](int b, int n) {
+        const int q = n >> 3, r = n & 7, x = b & 7;
+        return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    };
+    int item, chunk = 0, nrows = H;
+    if ((int)blockIdx.x < nfull) {
+        item = xcd_order(blockIdx.x, nfull);
+    } else {
+        const int id = xcd_order(blockIdx.x - nfull, total - nfull);
+        item = nfull + id / nchunks;
+        chunk = id % nchunks;
+        nrows = rows;
     }
-    const int strip = id % nstrips;
-    const int chunk = (id / nstrips) % nchunks;
+    const int strip = item % nstrips;
     // an odd last plane is simply done by both pipelines (identical stores)
-    const int d = min((id / (nstrips * nchunks)) * PPW + pipe, D - 1);
-    const int w0 = strip * OUTW, h0 = chunk * rows, h1 = min(h0 + rows, H);
+    const int d = min((item / nstrips) * PPW + pipe, D - 1);
+    const int w0 = strip * OUTW, h0 = chunk * nrows, h1 = min(h0 + nrows, H);
     const int ys = max(h0 - R, 0), ye = min(h1 - 1 + R, H - 1);
     const int nb = (h1 - 1 + R - ys + B) / B;   // batch k holds rows ys + k*B + (0..B-1)
     const size_t plane = (size_t)H * W;
@@ -675,36 +687,41 @@ template <int NSCAN, int NEMIT>
 static int launch_cbca_stream(const float *in, float *out, const Support *sup, int D, int H, int W, hipStream_t s)
 {
     const int nstrips = cdiv(W, s4::OUTW);
-    // Row chunks: a strip of one plane can be cut into row chunks (each re-stages 2R halo rows).  The launch wants
-    // tall chunks and a workgroup count that fills whole rounds of the chip's 2-per-CU resident slots; pick the chunk
-    // count with the best product of the two efficiencies, chunks never shorter than 64 rows.
+    // One workgroup per CU is resident (two planes, 158 KiB of LDS), and every (strip, plane group) costs the same, so
+    // the launch is a number of rounds.  items / slots is rarely whole: the whole rounds run at full height, and the
+    // remainder is cut into row chunks (each re-stages 2R halo rows, never shorter than 64 rows) so that it fills the
+    // chip too - e.g. 750x500x256: 384 items on 256 CUs = 256 full-height workgroups + 128 items in two halves,
+    // 526 + 276 staged rows per CU instead of 2 x 526 (one chunk) or 3 x 276 (everything in halves).
     static const int slots = [] {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             cus = 256;
-        return (2 / PPW) * (cus > 0 ? cus : 256);
+        cus = (2 / PPW) * (cus > 0 ? cus : 256);
+        return cus & ~7;                         // groups of 8: the two parts of the launch keep their XCD phase
     }();
     const int DG = cdiv(D, PPW);                 // plane groups
+    const long items = (long)nstrips * DG;
+    const long nfull = slots > 0 ? items / slots * slots : 0;
+    const long rem = items - nfull;
     int nchunks = 1;
-    double best = -1.0;
-    for (int n = 1; n <= max(1, min(H / 64, 16)); ++n) {
-        const double rounds = (double)nstrips * DG * n / slots;
-        const double fill = rounds / ceil(rounds);
-        const double rows_n = (double)H / n;
-        const double eff = fill * rows_n / (rows_n + 2 * s4::R);
-        if (eff > best + 1e-9) {
-            best = eff;
-            nchunks = n;
+    if (rem > 0) {
+        double best = 1e30;
+        for (int n = 1; n <= max(1, min(H / 64, 16)); ++n) {
+            const double cost = ceil((double)rem * n / slots) * ((double)H / n + 2 * s4::R);   // staged rows per CU
+            if (cost < best - 1e-9) {
+                best = cost;
+                nchunks = n;
+            }
         }
     }
     const int rows = cdiv(H, nchunks);
-    const long total = (long)nstrips * nchunks * DG;
+    const long total = nfull + rem * nchunks;
     MCCNN_REQUIRE(total <= 0x7fffffffL && (long)H * W * 8 <= 0x7fffffffL, MCCNN_E_UNSUPPORTED,
                   "mccnn_cbca_iter: image %dx%d / volume too large for 32-bit buffer offsets", W, H);
     hipLaunchKernelGGL((cbca_stream_kernel<NSCAN, NEMIT>), dim3((unsigned)total),
                        dim3(64 * PPW * (NSCAN + NHS + NEMIT)), 0, s, in, out, sup, D, H, W, rows, nstrips, nchunks,
-                       (int)total);
+                       (int)total, (int)nfull);
     return check_launch("mccnn_cbca_iter(stream)");
 }
 
