@@ -222,6 +222,7 @@ def main():
     # algorithmic bytes per launch (SURVEY 8d / DESIGN.md): one read + one write of every voxel the launch owns
     algo = {
         "cbca_iter": 2 * vol_bytes,       # one iteration on one volume
+        "cbca_iter_pair": 2 * 2 * vol_bytes,   # one iteration on BOTH volumes (one launch: left + right)
         "sgm_pass": 2 * 2 * vol_bytes,    # one direction on BOTH volumes (one launch advances left + right)
         "sgm_first_pass": 2 * 2 * vol_bytes,
     }

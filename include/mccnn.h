@@ -98,6 +98,15 @@ int mccnn_cross_region_list(const mccnn_support_t *support, int H, int W, int L,
 int mccnn_cbca_iter(const float *in, float *out, const mccnn_support_t *support, int D, int H, int W, int L, int order,
                     mccnn_stream_t stream);
 
+/* One iteration on the left AND the right volume (same D, H, W; each with its own support planes) - the reference's
+ * cost_volume_aggregation takes both views in one call (match.py:142, 154; pf:116-180 loops over the two).  Same
+ * results as two mccnn_cbca_iter calls; for MCCNN_CBCA_SEPARABLE with L <= 14 it is ONE launch whose workgroups are dealt
+ * the work of both volumes (fewer, fuller rounds: 750x500x256 is exactly three rounds of 256 workgroups), every
+ * other variant runs the two single-volume launches. */
+int mccnn_cbca_iter_pair(const float *in_left, float *out_left, const mccnn_support_t *support_left,
+                         const float *in_right, float *out_right, const mccnn_support_t *support_right, int D, int H,
+                         int W, int L, int order, mccnn_stream_t stream);
+
 /* The paper's support regions from BOTH views (sec. 4.1; the reference skips it, pf:122-144, 661-729 dead code).
  * Opt-in, changes the output: at disparity d every arm used at a pixel q is min(own arm at q, the other view's arm at
  * the partner q -/+ d) (side LEFT: x - d, RIGHT: x + d; partner outside the image: own arms).  Flat float32 running

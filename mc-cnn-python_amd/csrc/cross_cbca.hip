@@ -406,10 +406,19 @@ __device__ __forceinline__ void pipe_sync()
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// One launch aggregates up to two volumes of the same shape (the left and the right view's, each with its own
+// support planes): the work items of both are dealt from one pool, so 750x500x256 is 768 items = exactly three
+// rounds of 256 resident workgroups instead of 2 x (one round + a chunked half round).
+struct StreamJobs {
+    const float *in[2];
+    float *out[2];
+    const Support *sup[2];
+    int n;
+};
+
 template <int NSCAN, int NEMIT>
 __global__ __launch_bounds__(64 * PPW * (NSCAN + NHS + NEMIT)) void cbca_stream_kernel(
-    const float *__restrict__ in, float *__restrict__ out, const Support *__restrict__ sup, int D, int H, int W,
-    int rows, int nstrips, int nchunks, int total, int nfull)
+    const StreamJobs jobs, int D, int H, int W, int rows, int nstrips, int nchunks, int total, int nfull)
 {
     using namespace s4;
     constexpr int NPF = 4;                      // batches of loads every wave keeps in flight
@@ -441,6 +450,12 @@ __global__ __launch_bounds__(64 * PPW * (NSCAN + NHS + NEMIT)) void cbca_stream_
         chunk = id % nchunks;
         nrows = rows;
     }
+    const int per_job = nstrips * ((D + PPW - 1) / PPW);
+    const int job = item >= per_job;            // at most two jobs
+    item -= job * per_job;
+    const float *const in = job ? jobs.in[1] : jobs.in[0];
+    float *const out = job ? jobs.out[1] : jobs.out[0];
+    const Support *const sup = job ? jobs.sup[1] : jobs.sup[0];
     const int strip = item % nstrips;
     // an odd last plane is simply done by both pipelines (identical stores)
     const int d = min((item / nstrips) * PPW + pipe, D - 1);
@@ -684,7 +699,7 @@ __global__ __launch_bounds__(64 * PPW * (NSCAN + NHS + NEMIT)) void cbca_stream_
 }
 
 template <int NSCAN, int NEMIT>
-static int launch_cbca_stream(const float *in, float *out, const Support *sup, int D, int H, int W, hipStream_t s)
+static int launch_cbca_stream(const StreamJobs &jobs, int D, int H, int W, hipStream_t s)
 {
     const int nstrips = cdiv(W, s4::OUTW);
     // One workgroup per CU is resident (two planes, 158 KiB of LDS), and every (strip, plane group) costs the same, so
@@ -701,7 +716,7 @@ static int launch_cbca_stream(const float *in, float *out, const Support *sup, i
         return cus & ~7;                         // groups of 8: the two parts of the launch keep their XCD phase
     }();
     const int DG = cdiv(D, PPW);                 // plane groups
-    const long items = (long)nstrips * DG;
+    const long items = (long)nstrips * DG * jobs.n;
     const long nfull = slots > 0 ? items / slots * slots : 0;
     const long rem = items - nfull;
     int nchunks = 1;
@@ -720,7 +735,7 @@ static int launch_cbca_stream(const float *in, float *out, const Support *sup, i
     MCCNN_REQUIRE(total <= 0x7fffffffL && (long)H * W * 8 <= 0x7fffffffL, MCCNN_E_UNSUPPORTED,
                   "mccnn_cbca_iter: image %dx%d / volume too large for 32-bit buffer offsets", W, H);
     hipLaunchKernelGGL((cbca_stream_kernel<NSCAN, NEMIT>), dim3((unsigned)total),
-                       dim3(64 * PPW * (NSCAN + NHS + NEMIT)), 0, s, in, out, sup, D, H, W, rows, nstrips, nchunks,
+                       dim3(64 * PPW * (NSCAN + NHS + NEMIT)), 0, s, jobs, D, H, W, rows, nstrips, nchunks,
                        (int)total, (int)nfull);
     return check_launch("mccnn_cbca_iter(stream)");
 }
@@ -736,6 +751,20 @@ struct SupportInfo { int H, W, L; };
 std::mutex g_support_mu;
 std::unordered_map<const void *, SupportInfo> g_support;
 }  // namespace
+
+static int check_support_record(const mccnn_support_t *support, int H, int W, int L, const char *who)
+{
+    std::lock_guard<std::mutex> lock(g_support_mu);
+    const auto it = g_support.find(support);
+    if (it != g_support.end()) {
+        MCCNN_REQUIRE(it->second.H == H && it->second.W == W, MCCNN_E_INVALID,
+                      "%s: support plane was built for a %dx%d image, volume is %dx%d", who, it->second.W, it->second.H,
+                      W, H);
+        MCCNN_REQUIRE(it->second.L <= L, MCCNN_E_INVALID,
+                      "%s: support plane was built with distance %d, called with L=%d", who, it->second.L, L);
+    }
+    return 0;
+}
 
 extern "C" size_t mccnn_support_bytes(int H, int W)
 {
@@ -814,21 +843,37 @@ extern "C" int mccnn_cbca_iter(const float *in, float *out, const mccnn_support_
     MCCNN_REQUIRE(D <= 65535, MCCNN_E_UNSUPPORTED, "mccnn_cbca_iter: D=%d exceeds grid.z", D);
     MCCNN_REQUIRE(order == MCCNN_CBCA_SEPARABLE || order == MCCNN_CBCA_REFERENCE_ORDER, MCCNN_E_INVALID,
                   "mccnn_cbca_iter: unknown order %d", order);
-    {
-        std::lock_guard<std::mutex> lock(g_support_mu);
-        const auto it = g_support.find(support);
-        if (it != g_support.end()) {
-            MCCNN_REQUIRE(it->second.H == H && it->second.W == W, MCCNN_E_INVALID,
-                          "mccnn_cbca_iter: support plane was built for a %dx%d image, volume is %dx%d", it->second.W,
-                          it->second.H, W, H);
-            MCCNN_REQUIRE(it->second.L <= L, MCCNN_E_INVALID,
-                          "mccnn_cbca_iter: support plane was built with distance %d, called with L=%d", it->second.L, L);
-        }
-    }
+    if (const int rc = check_support_record(support, H, W, L, "mccnn_cbca_iter")) return rc;
     hipStream_t s = (hipStream_t)stream;
-    if (order == MCCNN_CBCA_SEPARABLE && L <= 14)
-        return launch_cbca_stream<CBCA_NSCAN, CBCA_NEMIT>(in, out, support, D, H, W, s);
+    if (order == MCCNN_CBCA_SEPARABLE && L <= 14) {
+        const StreamJobs jobs = {{in, nullptr}, {out, nullptr}, {support, nullptr}, 1};
+        return launch_cbca_stream<CBCA_NSCAN, CBCA_NEMIT>(jobs, D, H, W, s);
+    }
     if (L <= 14) return launch_cbca<13, 32>(in, out, support, D, H, W, order, s);
     if (L <= 32) return launch_cbca<31, 16>(in, out, support, D, H, W, order, s);
     MCCNN_REQUIRE(false, MCCNN_E_UNSUPPORTED, "mccnn_cbca_iter: L=%d > 32 not built", L);
+}
+
+extern "C" int mccnn_cbca_iter_pair(const float *in_left, float *out_left, const mccnn_support_t *support_left,
+                                    const float *in_right, float *out_right, const mccnn_support_t *support_right,
+                                    int D, int H, int W, int L, int order, mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(in_left && out_left && support_left && in_right && out_right && support_right, MCCNN_E_INVALID,
+                  "mccnn_cbca_iter_pair: null pointer");
+    MCCNN_REQUIRE(in_left != out_left && in_right != out_right && out_left != out_right && in_left != out_right &&
+                      in_right != out_left,
+                  MCCNN_E_INVALID, "mccnn_cbca_iter_pair: outputs must not alias an input or each other");
+    if (order == MCCNN_CBCA_SEPARABLE && L >= 1 && L <= 14 && D > 0 && H > 0 && W > 0 && D <= 65535) {
+        int rc = check_support_record(support_left, H, W, L, "mccnn_cbca_iter_pair");
+        if (rc) return rc;
+        rc = check_support_record(support_right, H, W, L, "mccnn_cbca_iter_pair");
+        if (rc) return rc;
+        const StreamJobs jobs = {{in_left, in_right}, {out_left, out_right}, {support_left, support_right}, 2};
+        return launch_cbca_stream<CBCA_NSCAN, CBCA_NEMIT>(jobs, D, H, W, (hipStream_t)stream);
+    }
+    // every other variant: the two single-volume launches, with their argument checks
+    const int rc = mccnn_cbca_iter(in_left, out_left, support_left, D, H, W, L, order, stream);
+    if (rc) return rc;
+    return mccnn_cbca_iter(in_right, out_right, support_right, D, H, W, L, order, stream);
 }

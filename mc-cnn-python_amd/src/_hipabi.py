@@ -36,6 +36,7 @@ SIGNATURES = {
     "mccnn_cross_arms": (_i, [_vp, _i, _i, _f, _i, _vp, _vp]),
     "mccnn_cross_region_list": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mccnn_cbca_iter": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mccnn_cbca_iter_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mccnn_cbca_iter_both": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mccnn_hwd_pitch": (_i, [_i]),
     "mccnn_dhw_to_hwd": (_i, [_vp, _vp, _i, _i, _i, _vp]),

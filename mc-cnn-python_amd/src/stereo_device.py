@@ -159,6 +159,31 @@ def cbca(vol, tmp, support, iterations, distance_threshold, order=hip.MCCNN_CBCA
     return src, dst
 
 
+def cbca_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, iterations, distance_threshold,
+              order=hip.MCCNN_CBCA_SEPARABLE, timer=None):
+    """cbca() on the left and the right volume together: every iteration is ONE launch that deals the work items of
+    both volumes from one pool (mccnn_cbca_iter_pair; same results as two cbca() calls, fewer and fuller rounds of
+    workgroups).  Returns ((result_l, spare_l), (result_r, spare_r))."""
+    D, H, W = vol_l.shape
+    if tuple(vol_r.shape) != (D, H, W):
+        raise ValueError("cbca_pair: the two volumes must have the same shape")
+    lib = hip.load()
+    for sup in (support_l, support_r):
+        have = sup.untyped_storage().nbytes() - sup.storage_offset() * sup.element_size()
+        if tuple(sup.shape) != (H, W) or not sup.is_contiguous() or have < lib.mccnn_support_bytes(H, W):
+            raise ValueError("cbca_pair: `support` must be the tensor cross_arms() returned")
+    (sl, dl), (sr, dr) = (vol_l, tmp_l), (vol_r, tmp_r)
+    timer = timer or _NO_TIMER
+    for _ in range(int(iterations)):
+        timer.start("cbca_iter_pair")
+        hip.check(lib.mccnn_cbca_iter_pair(hip.ptr(sl), hip.ptr(dl), hip.ptr(support_l), hip.ptr(sr), hip.ptr(dr),
+                                           hip.ptr(support_r), D, H, W, int(distance_threshold), int(order),
+                                           hip.stream()), "mccnn_cbca_iter_pair")
+        timer.stop()
+        sl, dl, sr, dr = dl, sl, dr, sr
+    return (sl, dl), (sr, dr)
+
+
 def cbca_both_views(vol, tmp, support_self, support_other, iterations, distance_threshold, side, timer=None):
     """`iterations` rounds of cross-based averaging with the paper's two-view support regions (opt-in extra, see
     mccnn_cbca_iter_both): arms intersected with the other view's at the partner pixel x -/+ d.  Same ping-pong
@@ -446,9 +471,15 @@ class StereoMatcher(object):
                 return cbca_both_views(vol, tmp, own, other, n, hp["cbca_distance"], side, timer)
             return cbca(vol, tmp, own, n, hp["cbca_distance"], self.cbca_order, timer)
 
+        def aggregate_both(lcv, t1d, rcv, t2d, n):
+            # the separable kernel takes both views in one launch; the other variants run view by view
+            if not ex["both_view_support"] and self.cbca_order == hip.MCCNN_CBCA_SEPARABLE:
+                return cbca_pair(lcv, t1d, sup_l, rcv, t2d, sup_r, n, hp["cbca_distance"], self.cbca_order, timer)
+            return (aggregate(lcv, t1d, sup_l, sup_r, n, hip.MCCNN_SIDE_LEFT),
+                    aggregate(rcv, t2d, sup_r, sup_l, n, hip.MCCNN_SIDE_RIGHT))
+
         t1d, t2d = ws["t1"][:nd].view(dhw), ws["t2"][:nd].view(dhw)
-        lcv, t1d = aggregate(lcv, t1d, sup_l, sup_r, hp["cbca_num_iterations1"], hip.MCCNN_SIDE_LEFT)
-        rcv, t2d = aggregate(rcv, t2d, sup_r, sup_l, hp["cbca_num_iterations1"], hip.MCCNN_SIDE_RIGHT)
+        (lcv, t1d), (rcv, t2d) = aggregate_both(lcv, t1d, rcv, t2d, hp["cbca_num_iterations1"])
         if keep is not None:
             keep["cbca1"] = (lcv.clone(), rcv.clone())
 
@@ -463,8 +494,7 @@ class StereoMatcher(object):
         if keep is not None:
             keep["sgm"] = (lcv.clone(), rcv.clone())
 
-        lcv, t1d = aggregate(lcv, t1d, sup_l, sup_r, hp["cbca_num_iterations2"], hip.MCCNN_SIDE_LEFT)
-        rcv, t2d = aggregate(rcv, t2d, sup_r, sup_l, hp["cbca_num_iterations2"], hip.MCCNN_SIDE_RIGHT)
+        (lcv, t1d), (rcv, t2d) = aggregate_both(lcv, t1d, rcv, t2d, hp["cbca_num_iterations2"])
         if keep is not None:
             keep["cbca2"] = (lcv.clone(), rcv.clone())
 

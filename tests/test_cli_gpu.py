@@ -98,7 +98,7 @@ def test_bench_world_size_one_through_rccl():
     d = json.loads(lines[0])
     assert d["process_group"] == "nccl x1", d["process_group"]
     assert d["n_gpus"] == 1 and d["config"]["launch"] == "one hipGraph replay per pair"
-    assert d["roofline"]["kernel"] == "cbca_iter" and 0.0 < d["roofline"]["frac"] < 1.5
+    assert d["roofline"]["kernel"] == "cbca_iter_pair" and 0.0 < d["roofline"]["frac"] < 1.5
     want = 256 * 256 * 64 * 1e-6 / (d["ms_per_step"] * 1e-3)
     assert abs(d["value"] - want) <= 0.02 * want
     assert d["ms_per_step_host_in_host_out"] > 0 and d["ms_per_step_kernel_by_kernel"] > 0

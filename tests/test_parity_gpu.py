@@ -413,6 +413,33 @@ def test_full_size_cbca_streaming_vs_reference_order_cfg2(sd):
         assert err <= 1e-6, "D=%d: streaming vs reference order differ by %g" % (D, err)
 
 
+@pytest.mark.parametrize("H,W,D,iters", [(500, 750, 256, 2), (375, 1242, 7, 3), (70, 300, 5, 1), (40, 33, 1, 2)])
+def test_cbca_pair_launch_equals_two_single_launches(sd, H, W, D, iters):
+    """mccnn_cbca_iter_pair (left + right volume dealt to one launch: whole rounds, chunked remainders, odd plane
+    counts, one-strip images) is bit-identical to mccnn_cbca_iter on each volume; a reference-order request through
+    the same entry point falls back to the two single launches."""
+    import _hipabi as hip
+    g = torch.Generator(device="cuda").manual_seed(11)
+    imgs = [torch.nn.functional.avg_pool2d(torch.rand((1, 1, H, W), device="cuda", generator=g), 5, 1, 2)[0, 0]
+            .contiguous() for _ in range(2)]
+    sups = [sd.cross_arms(im, 0.02, 14) for im in imgs]
+    vols = [-torch.rand((D, H, W), device="cuda", generator=g) for _ in range(2)]
+    single = [sd.cbca(v.clone(), torch.empty_like(v), s_, iters, 14, hip.MCCNN_CBCA_SEPARABLE)[0]
+              for v, s_ in zip(vols, sups)]
+    (pl, _), (pr, _) = sd.cbca_pair(vols[0].clone(), torch.empty_like(vols[0]), sups[0], vols[1].clone(),
+                                    torch.empty_like(vols[1]), sups[1], iters, 14, hip.MCCNN_CBCA_SEPARABLE)
+    assert torch.equal(pl, single[0]) and torch.equal(pr, single[1])
+    if D <= 8:
+        ref = [sd.cbca(v.clone(), torch.empty_like(v), s_, 1, 14, hip.MCCNN_CBCA_REFERENCE_ORDER)[0]
+               for v, s_ in zip(vols, sups)]
+        (ql, _), (qr, _) = sd.cbca_pair(vols[0].clone(), torch.empty_like(vols[0]), sups[0], vols[1].clone(),
+                                        torch.empty_like(vols[1]), sups[1], 1, 14, hip.MCCNN_CBCA_REFERENCE_ORDER)
+        assert torch.equal(ql, ref[0]) and torch.equal(qr, ref[1])
+    with pytest.raises(hip.MccnnHipError):      # outputs must not alias
+        t = torch.empty_like(vols[0])
+        sd.cbca_pair(vols[0], t, sups[0], vols[1], t, sups[1], 1, 14, hip.MCCNN_CBCA_SEPARABLE)
+
+
 def test_full_size_sgm_first_pass_equals_unfused_cfg2(sd):
     """750x500x256: mccnn_sgm_first_pass (layout change fused into direction (0,1)) is bit-identical to
     mccnn_dhw_to_hwd followed by mccnn_sgm_pass, for both sides in one launch."""

@@ -66,6 +66,12 @@ def main():
         print("%-22s %8.4f ms  %8.1f GB/s  %5.1f%% of HBM peak" % (name, ms, gbs, 100 * gbs / HBM_PEAK_GBS), flush=True)
 
     add("cbca_iter", lambda: sd.cbca(va, vb, sup, 1, 14, hip.MCCNN_CBCA_SEPARABLE), 2 * vol_bytes)
+    sup2 = sd.cross_arms(dr, 0.02, 14)
+    vc, vd = torch.empty_like(va), torch.empty_like(va)
+    vc.copy_(va)
+    add("cbca_iter_pair", lambda: sd.cbca_pair(va, vb, sup, vc, vd, sup2, 1, 14, hip.MCCNN_CBCA_SEPARABLE),
+        4 * vol_bytes)
+    del vc, vd
     add("cbca_iter_reforder", lambda: sd.cbca(va, vb, sup, 1, 14, hip.MCCNN_CBCA_REFERENCE_ORDER), 2 * vol_bytes)
     hwd = sd.dhw_to_hwd(va)
     hwd2 = sd.dhw_to_hwd(vb)
