@@ -190,6 +190,28 @@ int mccnn_conv1_pad_bias_relu(const float *images, const float *weights, const f
 int mccnn_l2norm_chw_to_hwc(const float *chw, const float *bias, float *hwc, int C, int H, int W,
                             mccnn_stream_t stream);
 
+/* ---- a1 on the matrix cores: split-operand 3x3 convolutions (opt-in; model.py:51-64) ----------------------------
+ * The 64 -> 64 map layers as an implicit GEMM on v_mfma_f32_32x32x16_f16 with every float32 operand carried as two
+ * f16 numbers (x * s = hi + lo, 22 significand bits; products hi*hi + hi*lo + lo*hi accumulated in float32): as close
+ * to a float64 evaluation as the float32 library convolutions, but not bit-identical to them, hence opt-in.
+ * "Split records": 256 bytes per pixel, [channel group q of 16][hi: 16 x f16 | lo: 16 x f16], pixel-major
+ * [N][H][W][256 B]; act_scale (a power of two, e.g. 256) is the factor the stored activations carry (they saturate
+ * at |x| * act_scale = 65504).
+ * mccnn_conv3x3_split_pack: weights [64][64][3][3] float32 (out, in, ky, kx) -> `packed`
+ *   (mccnn_conv3x3_split_weights_bytes() bytes) in MFMA fragment order, scaled by weight_scale (a power of two that
+ *   brings max |w| near 1024).
+ * mccnn_conv1_split: layer 1 (1 -> 64 maps) fused with the zero padding like mccnn_conv1_pad_bias_relu, writing
+ *   split records [N][H+2pad-2][W+2pad-2].
+ * mccnn_conv3x3_split: in [N][Hi][Wi] records -> VALID conv + bias; last == 0: ReLU, split records
+ *   [N][Hi-2][Wi-2]; last != 0: tf.nn.l2_normalize over the 64 maps, float32 [N][Hi-2][Wi-2][64] (what
+ *   mccnn_cost_volume reads). */
+size_t mccnn_conv3x3_split_weights_bytes(void);
+int mccnn_conv3x3_split_pack(const float *weights, float weight_scale, void *packed, mccnn_stream_t stream);
+int mccnn_conv1_split(const float *images, const float *weights, const float *bias, void *out, int N, int H, int W,
+                      int pad, float act_scale, mccnn_stream_t stream);
+int mccnn_conv3x3_split(const void *in, const void *packed_weights, const float *bias, void *out, int N, int Hi, int Wi,
+                        float weight_scale, float act_scale, int last, mccnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

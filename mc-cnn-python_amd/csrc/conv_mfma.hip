@@ -1,0 +1,391 @@
+// The 64 -> 64 map 3x3 VALID convolutions of the feature stack (model.py:51-61 of the reference; a1 in SURVEY 8) on the
+// matrix cores, as an opt-in alternative to the float32 library convolutions.
+//
+// Arithmetic.  gfx950 has no float32-input MFMA faster than v_mfma_f32_32x32x2_f32 (157 TFLOP/s, less than the
+// library's Winograd kernels deliver in effective terms), but 2.5 PFLOP/s of f16.  Every float32 operand x is carried
+// as two f16 numbers, x * s = hi + lo with hi = f16(x * s), lo = f16(x * s - hi) (s a power of two chosen so that
+// both parts stay normal numbers): 22 significand bits.  A product a * b becomes three MFMA terms
+//     a_hi * b_hi + a_hi * b_lo + a_lo * b_hi          (the a_lo * b_lo term is below 2^-22 relative)
+// accumulated in float32 by the matrix core.  Measured against a float64 evaluation of the stack the result is as
+// close as the float32 library path (tests/test_features_split_gpu.py records both) - it is float32-equivalent
+// arithmetic on f16 hardware, not a reduced-precision mode, but it is NOT bit-identical to any float32 evaluation
+// order, so it is selected explicitly (StereoMatcher(features="split_f16"), match.py --fast).
+//
+// Activations live in HBM as "split records": 256 bytes per pixel, [q = channel / 16][hi 16 x f16 | lo 16 x f16],
+// pixel-major ([N][H][W][256 B]).  A record has the size of the pixel's 64 float32 values; the last layer writes those
+// (L2-normalised, tf.nn.l2_normalize, model.py:64) in the same place-value layout [N][H][W][64] the cost volume reads.
+//
+// conv3x3_split_kernel - implicit GEMM, M = 64 output maps (A = weights), N = pixels (B = activations), K = 9 taps x
+// 64 input maps, v_mfma_f32_32x32x16_f16.  A workgroup (4 waves, one per SIMD) owns a tile of 16 x 32 output pixels;
+// wave w the rows 4w .. 4w+3, one row of 32 pixels per MFMA column block: 4 pixel blocks x 2 map blocks = 8
+// accumulators (128 registers).  The K loop runs over channel groups q of 16 (one MFMA K step) and the 9 taps:
+//   * B: the 18 x 34 input pixels of the tile, channel group q only, are staged in LDS (80-byte slots: hi 32 B, lo
+//     32 B, 16 B pad - conflict-free ds_read_b128 for 32 consecutive pixels); a tap is an immediate offset.  Two
+//     buffers: group q+1 (or the next tile's group 0) is fetched into registers while group q is multiplied, and
+//     written to the other buffer before the one barrier per group.
+//   * A: packed on the device once per weight set (mccnn_conv3x3_split_pack) in fragment order, 1 KiB per (K step,
+//     part, map block), read from global memory (L1/L2 resident: 144 KiB per layer) two K steps ahead.
+//   * per K step and wave: 4 A fragments, 8 B fragments, 24 MFMAs (768 cycles of the SIMD's matrix core).
+// Epilogue: x / (s_a s_w) + bias, ReLU, split again (or L2-normalise), through a per-wave LDS scratch so that the
+// stores are whole 256-byte records, 1 KiB per wave instruction.
+// Persistent launch: one workgroup per CU walks tiles in an XCD-contiguous order (neighbouring tiles share halo
+// pixels in one L2).
+#include "common.h"
+
+namespace mccnn {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f16x __attribute__((ext_vector_type(16)));
+typedef uint32_t w4 __attribute__((ext_vector_type(4)));
+typedef uint32_t w2 __attribute__((ext_vector_type(2)));
+
+namespace cs {
+constexpr int TH = 16, TW = 32;              // output tile
+constexpr int IH = TH + 2, IW = TW + 2;      // input pixels of a tile
+constexpr int NPIX = IH * IW;                // 612
+constexpr int SLOT = 80;                     // LDS bytes per staged pixel (one channel group): hi 32, lo 32, pad 16
+constexpr int QBUF = NPIX * SLOT;            // 48 960
+constexpr int NITEM = NPIX * 4;              // 16-byte pieces per staged group
+constexpr int NST = (NITEM + 255) / 256;     // 10 per thread
+constexpr int EPITCH = 272;                  // epilogue scratch: 256-byte record + 16 (keeps b128 alignment)
+constexpr int EPI = 32 * EPITCH;             // per wave: one row of 32 pixels
+constexpr int LDS_BYTES = 2 * QBUF + 4 * EPI;   // 132 736
+constexpr int REC = 256;                     // bytes per pixel record
+constexpr int WFRAG = 1024;                  // bytes per packed weight fragment
+constexpr int WLAYER = 36 * 4 * WFRAG;       // packed weights of one layer
+}  // namespace cs
+
+__device__ __forceinline__ void split4(const float y[4], float scale, w2 &hi, w2 &lo)
+{
+    h4 a, b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float v = fminf(fmaxf(y[j] * scale, -65504.f), 65504.f);   // saturate instead of inf (|x| < 65504 / s)
+        const _Float16 h = (_Float16)v;
+        a[j] = h;
+        b[j] = (_Float16)(v - (float)h);
+    }
+    hi = __builtin_bit_cast(w2, a);
+    lo = __builtin_bit_cast(w2, b);
+}
+
+// weights [64 out][64 in][3][3] float32 (torch layout) -> fragment order:
+// [ks = q*9 + tap][part: hi, lo][map block mb][lane][8 x f16], lane: out = 32 mb + (lane & 31), in = 16 q + 8 (lane >> 5) + j
+__global__ __launch_bounds__(256) void conv3x3_split_pack_kernel(const float *__restrict__ w, float scale,
+                                                                 _Float16 *__restrict__ packed)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;          // one (ks, mb, lane)
+    if (i >= 36 * 2 * 64) return;
+    const int lane = i & 63, mb = (i >> 6) & 1, ks = i >> 7;
+    const int q = ks / 9, tap = ks - q * 9;
+    const int oc = 32 * mb + (lane & 31), ic0 = 16 * q + 8 * (lane >> 5);
+    h8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = w[((size_t)oc * 64 + ic0 + j) * 9 + tap] * scale;
+        const _Float16 h = (_Float16)v;
+        hi[j] = h;
+        lo[j] = (_Float16)(v - (float)h);
+    }
+    h8 *p = reinterpret_cast<h8 *>(packed);
+    p[((ks * 2 + 0) * 2 + mb) * 64 + lane] = hi;
+    p[((ks * 2 + 1) * 2 + mb) * 64 + lane] = lo;
+}
+
+// Layer 1 (1 -> 64 maps) on the zero-padded image (process_functional.py:20-25), bias, ReLU, written as split records.
+// Thread = (pixel, channel group of 16): the same float32 multiply-adds as mccnn_conv1_pad_bias_relu, then the split.
+__global__ __launch_bounds__(256) void conv1_split_kernel(const float *__restrict__ img, const float *__restrict__ w,
+                                                          const float *__restrict__ bias, char *__restrict__ out, int H,
+                                                          int W, int pad, int Ho, int Wo, float act_scale)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int q = t & 3, xo = t >> 2;
+    const int yo = blockIdx.y, n = blockIdx.z;
+    if (xo >= Wo) return;
+    float v[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int y = yo + i - pad, x = xo + j - pad;
+            v[i * 3 + j] = (y >= 0 && y < H && x >= 0 && x < W) ? img[((size_t)n * H + y) * W + x] : 0.f;
+        }
+    char *rec = out + (((size_t)n * Ho + yo) * Wo + xo) * cs::REC + q * 64;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 16 * q + 4 * g + j;
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc += w[c * 9 + k] * v[k];
+            acc += bias[c];
+            y[j] = fmaxf(acc, 0.f);
+        }
+        w2 hi, lo;
+        split4(y, act_scale, hi, lo);
+        *reinterpret_cast<w2 *>(rec + 8 * g) = hi;
+        *reinterpret_cast<w2 *>(rec + 32 + 8 * g) = lo;
+    }
+}
+
+// MODE 0: bias + ReLU, split records out.  MODE 1: bias, L2 normalisation over the 64 maps, float32 [N][Ho][Wo][64] out.
+template <int MODE>
+__global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restrict__ in, const char *__restrict__ wpk,
+                                                            const float *__restrict__ bias, char *__restrict__ out,
+                                                            int N, int Hi, int Wi, float inv_scale, float act_scale,
+                                                            int tiles_x, int tiles_y, int total)
+{
+    using namespace cs;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Ho = Hi - 2, Wo = Wi - 2;
+    const size_t in_bytes = (size_t)N * Hi * Wi * REC, out_bytes = (size_t)N * Ho * Wo * REC;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(in), 0, (int)in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wpk), 0, WLAYER, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+        out, 0, (int)out_bytes, 0x00020000);
+
+    // staging pieces of this thread: piece i = r*256 + tid -> pixel i >> 2 of the 18 x 34 input tile, 16-byte part i & 3
+    int goff[NST], loff[NST];
+#pragma unroll
+    for (int r = 0; r < NST; ++r) {
+        const int i = r * 256 + tid, p = min(i >> 2, NPIX - 1), part = i & 3;
+        const int py = p / IW, px = p - py * IW;
+        goff[r] = (py * Wi + px) * REC + part * 16;
+        loff[r] = p * SLOT + part * 16;
+    }
+    const bool last_piece = (NST - 1) * 256 + tid < NITEM;
+
+    // XCD-contiguous tile order (see cross_cbca.hip): virtual block v = blockIdx + i * gridDim keeps its XCD
+    auto xcd_order = [](int b, int n) {
+        const int q = n >> 3, r = n & 7, x = b & 7;
+        return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    };
+    auto tile_base = [&](int v, int &n, int &ty0, int &tx0) {
+        const int t = xcd_order(v, total);
+        const int tx = t % tiles_x, r = t / tiles_x;
+        const int ty = r % tiles_y;
+        n = r / tiles_y;
+        ty0 = ty * TH;
+        tx0 = tx * TW;
+    };
+
+    w4 st[NST];
+    auto fetch = [&](int n, int ty0, int tx0, int q) {
+        const int so = ((n * Hi + ty0) * Wi + tx0) * REC + q * 64;     // wave-uniform
+#pragma unroll
+        for (int r = 0; r < NST; ++r) st[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, goff[r], so, 0);
+    };
+    auto commit = [&](int buf) {
+        char *b = lds + buf * QBUF;
+#pragma unroll
+        for (int r = 0; r < NST; ++r)
+            if (r < NST - 1 || last_piece) *reinterpret_cast<w4 *>(b + loff[r]) = st[r];
+    };
+
+    int v = blockIdx.x;
+    if (v >= total) return;
+    int n, ty0, tx0;
+    tile_base(v, n, ty0, tx0);
+    fetch(n, ty0, tx0, 0);
+    commit(0);
+    __syncthreads();
+
+    // A fragments: slot ks % 3, fetched two K steps ahead (the weights are the same for every tile, so the stream
+    // simply wraps)
+    w4 af[3][4];
+    auto fetch_a = [&](int slot, int ks) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+            af[slot][f] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16, (ks * 4 + f) * WFRAG, 0);
+    };
+    fetch_a(0, 0);
+    fetch_a(1, 1);
+
+    const int bfrag = (wave * 4 * IW + (lane & 31)) * SLOT + 16 * (lane >> 5);
+    char *const epi = lds + 2 * QBUF + wave * EPI;
+
+    while (true) {
+        f16x acc[4][2];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[nb][mb][i] = 0.f;
+        const int vn = v + gridDim.x;
+        int nn = 0, nty0 = 0, ntx0 = 0;
+        if (vn < total) tile_base(vn, nn, nty0, ntx0);
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {
+            // next channel group of this tile, or group 0 of the next tile, into registers
+            if (q < 3)
+                fetch(n, ty0, tx0, q + 1);
+            else if (vn < total)
+                fetch(nn, nty0, ntx0, 0);
+            const char *bq = lds + (q & 1) * QBUF + bfrag;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ks = q * 9 + tap;
+                int ks2 = ks + 2;
+                ks2 = ks2 >= 36 ? ks2 - 36 : ks2;
+                fetch_a((tap + 2) % 3, ks2);
+                const int slot = tap % 3;
+                const int dy = tap / 3, dx = tap - dy * 3;
+                const h8 a_hi0 = __builtin_bit_cast(h8, af[slot][0]), a_hi1 = __builtin_bit_cast(h8, af[slot][1]);
+                const h8 a_lo0 = __builtin_bit_cast(h8, af[slot][2]), a_lo1 = __builtin_bit_cast(h8, af[slot][3]);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    const char *pb = bq + ((nb + dy) * IW + dx) * SLOT;
+                    const h8 b_hi = __builtin_bit_cast(h8, *reinterpret_cast<const w4 *>(pb));
+                    const h8 b_lo = __builtin_bit_cast(h8, *reinterpret_cast<const w4 *>(pb + 32));
+                    acc[nb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo0, b_hi, acc[nb][0], 0, 0, 0);
+                    acc[nb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo1, b_hi, acc[nb][1], 0, 0, 0);
+                    acc[nb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi0, b_lo, acc[nb][0], 0, 0, 0);
+                    acc[nb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi1, b_lo, acc[nb][1], 0, 0, 0);
+                    acc[nb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi0, b_hi, acc[nb][0], 0, 0, 0);
+                    acc[nb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi1, b_hi, acc[nb][1], 0, 0, 0);
+                }
+            }
+            if (q < 3 || vn < total) commit((q + 1) & 1);
+            __syncthreads();
+        }
+
+        // ---- epilogue: this wave's four rows of 32 pixels ----
+        const int px = lane & 31, half = lane >> 5;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            float y[2][16];
+            float ss = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const float t = acc[nb][mb][r] * inv_scale + bias[ch];
+                    y[mb][r] = MODE == 0 ? fmaxf(t, 0.f) : t;
+                    if (MODE == 1) ss = fmaf(t, t, ss);
+                }
+            float nrm = 1.f;
+            if (MODE == 1) {
+                ss += __shfl_xor(ss, 32);
+                nrm = 1.f / sqrtf(fmaxf(ss, 1e-12f));
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = 32 * mb + 8 * g + 4 * half;          // first of 4 consecutive maps
+                    if (MODE == 0) {
+                        w2 hi, lo;
+                        split4(&y[mb][4 * g], act_scale, hi, lo);
+                        char *p = epi + px * EPITCH + (ch >> 4) * 64 + (ch & 15) * 2;
+                        *reinterpret_cast<w2 *>(p) = hi;
+                        *reinterpret_cast<w2 *>(p + 32) = lo;
+                    } else {
+                        w4 o;
+                        o.x = __float_as_uint(y[mb][4 * g + 0] * nrm);
+                        o.y = __float_as_uint(y[mb][4 * g + 1] * nrm);
+                        o.z = __float_as_uint(y[mb][4 * g + 2] * nrm);
+                        o.w = __float_as_uint(y[mb][4 * g + 3] * nrm);
+                        *reinterpret_cast<w4 *>(epi + px * EPITCH + ch * 4) = o;
+                    }
+                }
+            __builtin_amdgcn_wave_barrier();
+            const int row = ty0 + wave * 4 + nb;
+            const int so = ((n * Ho + row) * Wo + tx0) * REC;            // wave-uniform
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int i = it * 64 + lane, p = i >> 4, part = i & 15;
+                const w4 o = *reinterpret_cast<const w4 *>(epi + p * EPITCH + part * 16);
+                const bool ok = row < Ho && tx0 + p < Wo;
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, ok ? p * REC + part * 16 : 0x7ffffff0, so, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (vn >= total) break;
+        v = vn;
+        n = nn;
+        ty0 = nty0;
+        tx0 = ntx0;
+    }
+}
+
+}  // namespace mccnn
+
+extern "C" size_t mccnn_conv3x3_split_weights_bytes(void) { return (size_t)mccnn::cs::WLAYER; }
+
+extern "C" int mccnn_conv3x3_split_pack(const float *weights, float weight_scale, void *packed, mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(weights && packed, MCCNN_E_INVALID, "mccnn_conv3x3_split_pack: null pointer");
+    MCCNN_REQUIRE(weight_scale > 0.f, MCCNN_E_INVALID, "mccnn_conv3x3_split_pack: scale must be positive");
+    hipLaunchKernelGGL(conv3x3_split_pack_kernel, dim3(cdiv(36 * 2 * 64, 256)), dim3(256), 0, (hipStream_t)stream,
+                       weights, weight_scale, reinterpret_cast<_Float16 *>(packed));
+    return check_launch("mccnn_conv3x3_split_pack");
+}
+
+extern "C" int mccnn_conv1_split(const float *images, const float *weights, const float *bias, void *out, int N, int H,
+                                 int W, int pad, float act_scale, mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(images && weights && bias && out, MCCNN_E_INVALID, "mccnn_conv1_split: null pointer");
+    MCCNN_REQUIRE(N > 0 && H > 0 && W > 0 && pad >= 0, MCCNN_E_INVALID, "mccnn_conv1_split: bad size");
+    MCCNN_REQUIRE(act_scale > 0.f, MCCNN_E_INVALID, "mccnn_conv1_split: scale must be positive");
+    const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
+    MCCNN_REQUIRE(Ho > 0 && Wo > 0 && Ho <= 65535 && N <= 65535, MCCNN_E_UNSUPPORTED,
+                  "mccnn_conv1_split: output %dx%d outside the grid", Wo, Ho);
+    hipLaunchKernelGGL(conv1_split_kernel, dim3(cdiv(4L * Wo, 256), Ho, N), dim3(256), 0, (hipStream_t)stream, images,
+                       weights, bias, reinterpret_cast<char *>(out), H, W, pad, Ho, Wo, act_scale);
+    return check_launch("mccnn_conv1_split");
+}
+
+extern "C" int mccnn_conv3x3_split(const void *in, const void *packed_weights, const float *bias, void *out, int N,
+                                   int Hi, int Wi, float weight_scale, float act_scale, int last,
+                                   mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    using namespace cs;
+    MCCNN_REQUIRE(in && packed_weights && bias && out, MCCNN_E_INVALID, "mccnn_conv3x3_split: null pointer");
+    MCCNN_REQUIRE(N > 0 && Hi > 2 && Wi > 2, MCCNN_E_INVALID, "mccnn_conv3x3_split: input %dx%d too small", Wi, Hi);
+    MCCNN_REQUIRE(weight_scale > 0.f && act_scale > 0.f, MCCNN_E_INVALID, "mccnn_conv3x3_split: scales must be positive");
+    MCCNN_REQUIRE((size_t)N * Hi * Wi * REC <= 0x7ffffff0u, MCCNN_E_UNSUPPORTED,
+                  "mccnn_conv3x3_split: %d x %dx%d records exceed 32-bit buffer offsets", N, Wi, Hi);
+    const int Ho = Hi - 2, Wo = Wi - 2;
+    const int tiles_x = cdiv(Wo, TW), tiles_y = cdiv(Ho, TH);
+    const long total = (long)tiles_x * tiles_y * N;
+    MCCNN_REQUIRE(total <= 0x7fffffffL, MCCNN_E_UNSUPPORTED, "mccnn_conv3x3_split: too many tiles");
+    static const int cus = [] {
+        int dev = 0, c = 256;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0)
+            c = 256;
+        return c & ~7;
+    }();
+    const int grid = (int)(total < cus ? total : cus);
+    const float inv = 1.f / (weight_scale * act_scale);
+    hipStream_t s = (hipStream_t)stream;
+    if (last) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_split_kernel<1>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        MCCNN_REQUIRE(attr == hipSuccess, MCCNN_E_UNSUPPORTED, "mccnn_conv3x3_split: %d bytes of LDS refused", LDS_BYTES);
+        hipLaunchKernelGGL(conv3x3_split_kernel<1>, dim3(grid), dim3(256), LDS_BYTES, s,
+                           reinterpret_cast<const char *>(in), reinterpret_cast<const char *>(packed_weights), bias,
+                           reinterpret_cast<char *>(out), N, Hi, Wi, inv, act_scale, tiles_x, tiles_y, (int)total);
+    } else {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_split_kernel<0>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        MCCNN_REQUIRE(attr == hipSuccess, MCCNN_E_UNSUPPORTED, "mccnn_conv3x3_split: %d bytes of LDS refused", LDS_BYTES);
+        hipLaunchKernelGGL(conv3x3_split_kernel<0>, dim3(grid), dim3(256), LDS_BYTES, s,
+                           reinterpret_cast<const char *>(in), reinterpret_cast<const char *>(packed_weights), bias,
+                           reinterpret_cast<char *>(out), N, Hi, Wi, inv, act_scale, tiles_x, tiles_y, (int)total);
+    }
+    return check_launch("mccnn_conv3x3_split");
+}

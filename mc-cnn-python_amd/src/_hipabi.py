@@ -56,6 +56,10 @@ SIGNATURES = {
     "mccnn_bilateral": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _vp, _vp]),
     "mccnn_bias_act": (_i, [_vp, _vp, _i, _i, ctypes.c_long, _i, _vp]),
     "mccnn_conv1_pad_bias_relu": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mccnn_conv3x3_split_weights_bytes": (_sz, []),
+    "mccnn_conv3x3_split_pack": (_i, [_vp, _f, _vp, _vp]),
+    "mccnn_conv1_split": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "mccnn_conv3x3_split": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
     "mccnn_l2norm_chw_to_hwc": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
 }
 

@@ -165,6 +165,35 @@ class NET(object):
         out = self._convs_device(image_hw[None], pad)[0]      # [64,H,W] without the last bias
         return stereo_device.l2norm_chw_to_hwc(out, self.biases[-1])
 
+    def _split_weights(self):
+        """Packed f16 hi/lo weights of layers 2..n for the split-operand kernels, rebuilt when a weight tensor changes."""
+        import stereo_device
+        key = tuple((w.data_ptr(), w._version) for w in self.weights[1:])
+        cache = getattr(self, "_split_cache", None)
+        if cache is None or cache[0] != key:
+            cache = (key, [stereo_device.conv3x3_split_pack(w) for w in self.weights[1:]])
+            self._split_cache = cache
+        return cache[1]
+
+    def features_pair_hwc_split(self, left_hw, right_hw):
+        """features_pair_hwc on the matrix cores (csrc/conv_mfma.hip): every float32 operand as two f16 numbers, three
+        MFMA products per multiply, float32 accumulation - as close to a float64 evaluation as the library path, not
+        bit-identical to it (opt-in: StereoMatcher(features="split_f16"), match.py --fast).  Needs the 64-map 3x3
+        topology with at least two layers; activations must stay below 65504 / 256 in magnitude."""
+        import stereo_device
+        pad = (self.input_patch_size - 1) // 2
+        assert pad == self.num_conv_layers * (self.conv_kernel_size - 1) // 2
+        if self.conv_kernel_size != 3 or self.num_conv_feature_maps != 64 or self.num_conv_layers < 2:
+            raise ValueError("the split-operand feature kernels are built for >= 2 layers of 64 maps, 3x3")
+        packed = self._split_weights()
+        pair = torch.stack((left_hw, right_hw)).contiguous()
+        x = stereo_device.conv1_split(pair, self.weights[0].detach().contiguous(), self.biases[0].detach(), pad)
+        nl = self.num_conv_layers
+        for k in range(1, nl):
+            pk, ws = packed[k - 1]
+            x = stereo_device.conv3x3_split(x, pk, ws, self.biases[k].detach(), last=(k == nl - 1))
+        return x[0], x[1]
+
     def features_pair_hwc(self, left_hw, right_hw, tile_rows=None):
         """Both views through the shared-weight stack as one batch of two (the Siamese towers are the same weights,
         model.py:98 AUTO_REUSE / train.py:76-78): half the launches, twice the work per launch.

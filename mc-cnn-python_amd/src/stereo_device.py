@@ -85,6 +85,48 @@ def l2norm_chw_to_hwc(chw, bias=None, out=None):
     return out
 
 
+# ---- a1 on the matrix cores (opt-in): split-operand convolutions, csrc/conv_mfma.hip ---------------------------------
+SPLIT_ACT_SCALE = 256.0   # stored activations carry this factor (power of two); they saturate at |x| = 65504 / 256
+
+
+def conv3x3_split_pack(weight):
+    """weight [64,64,3,3] (torch layout) -> (packed device buffer, weight_scale) for conv3x3_split.  Reads max |w|
+    back to the host to choose the power-of-two scale: call once per weight set, not per image."""
+    assert tuple(weight.shape) == (64, 64, 3, 3), "the split-operand kernel is built for 64 -> 64 maps, 3x3"
+    w = weight.detach().contiguous().float()
+    m = float(w.abs().max())
+    scale = 2.0 ** math.floor(math.log2(1024.0 / m)) if m > 0.0 and math.isfinite(m) else 1.0
+    lib = hip.load()
+    packed = torch.empty((lib.mccnn_conv3x3_split_weights_bytes(),), dtype=torch.uint8, device=w.device)
+    hip.check(lib.mccnn_conv3x3_split_pack(hip.ptr(w), scale, hip.ptr(packed), hip.stream()), "mccnn_conv3x3_split_pack")
+    return packed, scale
+
+
+def conv1_split(images, weight, bias, pad, act_scale=SPLIT_ACT_SCALE):
+    """images [N,H,W] -> split records [N,H+2pad-2,W+2pad-2,256] (uint8 view): padding + layer 1 + bias + ReLU."""
+    N, H, W = images.shape
+    assert tuple(weight.shape) == (64, 1, 3, 3) and images.is_contiguous() and weight.is_contiguous()
+    out = torch.empty((N, H + 2 * pad - 2, W + 2 * pad - 2, 256), dtype=torch.uint8, device=images.device)
+    hip.check(hip.load().mccnn_conv1_split(hip.ptr(images), hip.ptr(weight), hip.ptr(bias), hip.ptr(out), N, H, W,
+                                           int(pad), float(act_scale), hip.stream()), "mccnn_conv1_split")
+    return out
+
+
+def conv3x3_split(x, packed, weight_scale, bias, last, act_scale=SPLIT_ACT_SCALE):
+    """x: split records [N,Hi,Wi,256] -> VALID 3x3 conv + bias; last=False: ReLU, records [N,Hi-2,Wi-2,256];
+    last=True: L2-normalised float32 features [N,Hi-2,Wi-2,64]."""
+    N, Hi, Wi, rec = x.shape
+    assert rec == 256 and x.dtype == torch.uint8 and x.is_contiguous()
+    if last:
+        out = torch.empty((N, Hi - 2, Wi - 2, 64), dtype=torch.float32, device=x.device)
+    else:
+        out = torch.empty((N, Hi - 2, Wi - 2, 256), dtype=torch.uint8, device=x.device)
+    hip.check(hip.load().mccnn_conv3x3_split(hip.ptr(x), hip.ptr(packed), hip.ptr(bias), hip.ptr(out), N, Hi, Wi,
+                                             float(weight_scale), float(act_scale), 1 if last else 0, hip.stream()),
+              "mccnn_conv3x3_split")
+    return out
+
+
 # ---- a2 ----------------------------------------------------------------------------------------------------------
 def cost_volume(fl, fr, ndisp, mode=hip.MCCNN_CV_EXACT, out=None):
     H, W, C = fl.shape
@@ -392,7 +434,7 @@ class StereoMatcher(object):
     """
 
     def __init__(self, net, hp=None, cv_mode=hip.MCCNN_CV_EXACT, cbca_order=hip.MCCNN_CBCA_SEPARABLE,
-                 feature_tile_rows=None, extras=None):
+                 feature_tile_rows=None, extras=None, features="miopen"):
         self.device = hip.require_device()
         self.net = net
         self.hp = dict(DEFAULT_HP)
@@ -401,6 +443,12 @@ class StereoMatcher(object):
         self.cv_mode = cv_mode
         self.cbca_order = cbca_order
         self.feature_tile_rows = feature_tile_rows   # None: whole image; else NET.features_pair_hwc's band height
+        # "miopen": float32 library convolutions; "split_f16": the split-operand matrix-core kernels (conv_mfma.hip)
+        if features not in ("miopen", "split_f16"):
+            raise ValueError("features must be 'miopen' or 'split_f16'")
+        if features == "split_f16" and feature_tile_rows is not None:
+            raise ValueError("row banding is implemented for the library convolutions only")
+        self.features = features
         # opt-in departures from the reference (they change the output): the paper's rules it leaves out, and the
         # scalar promotion of the NumPy it was written for
         self.extras = dict(both_view_support=False, interpolation_directions=4, occlusion_from_left=False,
@@ -449,7 +497,10 @@ class StereoMatcher(object):
         nd, nh = D * H * W, H * W * hwd[2]
 
         timer.start("features")
-        fl, fr = self.net.features_pair_hwc(L, R, tile_rows=self.feature_tile_rows)
+        if self.features == "split_f16":
+            fl, fr = self.net.features_pair_hwc_split(L, R)
+        else:
+            fl, fr = self.net.features_pair_hwc(L, R, tile_rows=self.feature_tile_rows)
         timer.stop()
 
         timer.start("cost_volume")

@@ -1,0 +1,141 @@
+"""GPU: the split-operand (f16 hi/lo, three MFMA products) feature stack of csrc/conv_mfma.hip - SURVEY 8 a1, opt-in.
+
+Checker: the same network evaluated in float64 by torch on the CPU (conv2d VALID on the once-padded image, ReLU,
+tf.nn.l2_normalize - model.py:51-64 of the reference as model.NET restates it).  The float32 library path (MIOpen) is
+measured against the same float64 values; the split path has to be as close, and both inside the 1e-5 bound the golden
+feature test uses.  The golden features themselves (float64-accumulating restatement of the reference) are checked too.
+Measured numbers go to gpurun_out/parity_features_split.json."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def features_float64(net, img):
+    """[H,W] float32 image -> [H,W,64] float64 unit features on the CPU."""
+    pad = (net.input_patch_size - 1) // 2
+    x = F.pad(img.double().cpu()[None, None], (pad, pad, pad, pad))
+    nl = net.num_conv_layers
+    for k in range(nl):
+        x = F.conv2d(x, net.weights[k].detach().double().cpu(), net.biases[k].detach().double().cpu())
+        if k < nl - 1:
+            x = F.relu(x)
+    x = x[0].permute(1, 2, 0)
+    return x / torch.sqrt(torch.clamp((x * x).sum(-1, keepdim=True), min=1e-12))
+
+
+def smooth_pair(H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    a = F.avg_pool2d(torch.randn((1, 1, H + 8, W + 8), generator=g), 5, 1, 2)[0, 0, 4:-4, 4:-4]
+    b = torch.roll(a, 3, 1) + 0.05 * torch.randn((H, W), generator=g)
+    out = []
+    for t in (a, b):
+        out.append(((t - t.mean()) / t.std()).float().contiguous())
+    return out
+
+
+@pytest.fixture(scope="module")
+def pf():
+    import _hipabi
+    _hipabi.require_device()
+    import process_functional
+    return process_functional
+
+
+@pytest.fixture(scope="module")
+def sd():
+    import stereo_device
+    return stereo_device
+
+
+@pytest.fixture(scope="module")
+def nets(net_layers):
+    from model import NET
+    trained = NET(None, input_patch_size=11, batch_size=1, device="cuda").set_layers(net_layers)
+    random_init = NET(None, input_patch_size=11, batch_size=1, device="cuda", seed=3)
+    return {"converted reference checkpoint": trained, "random init": random_init}
+
+
+@pytest.mark.parametrize("H,W", [(16, 32), (37, 61), (120, 200), (75, 333)])
+def test_split_features_as_close_to_float64_as_the_library_path(nets, H, W):
+    record = {}
+    for name, net in nets.items():
+        L, R = smooth_pair(H, W, 7)
+        ref = [features_float64(net, L), features_float64(net, R)]
+        lib = net.features_pair_hwc(L.cuda(), R.cuda())
+        spl = net.features_pair_hwc_split(L.cuda(), R.cuda())
+        assert spl[0].shape == (H, W, 64) and spl[0].dtype == torch.float32 and spl[0].is_contiguous()
+        e_lib = max(float((lib[i].double().cpu() - ref[i]).abs().max()) for i in range(2))
+        e_spl = max(float((spl[i].double().cpu() - ref[i]).abs().max()) for i in range(2))
+        record["%s %dx%d" % (name, W, H)] = {"library_fp32_max_abs_err": e_lib, "split_f16_max_abs_err": e_spl}
+        # unit vectors: absolute error = error relative to the vector norm.  Measured: library 3-5e-7, split 2-6e-7
+        assert e_spl <= 2e-6, "%s: split path %g from float64" % (name, e_spl)
+        assert e_spl <= max(3.0 * e_lib, 1e-6), "%s: split %g vs library %g" % (name, e_spl, e_lib)
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "parity_features_split.json")
+    old = {}
+    if os.path.isfile(path):
+        with open(path) as f:
+            old = json.load(f)
+    old.update(record)
+    with open(path, "w") as f:
+        json.dump(old, f, indent=1, sort_keys=True)
+
+
+def test_split_features_golden(pf, golden_cases, net_layers):
+    """Same bound as test_golden_features (1e-5 against the float64-accumulating restatement of the reference)."""
+    from model import NET
+    net = NET(None, input_patch_size=11, batch_size=1, device="cuda").set_layers(net_layers)
+    for name, g in golden_cases:
+        left = dev(g["left"]).reshape(g["left"].shape[0], g["left"].shape[1])
+        right = dev(g["right"]).reshape(g["right"].shape[0], g["right"].shape[1])
+        fl, fr = net.features_pair_hwc_split(left, right)
+        assert np.abs(fl.cpu().numpy() - g["fl"]).max() <= 1e-5, name
+        assert np.abs(fr.cpu().numpy() - g["fr"]).max() <= 1e-5, name
+
+
+def test_split_weights_follow_weight_updates(nets):
+    """The packed f16 weights are rebuilt when a weight tensor changes in place (training, set_layers)."""
+    net = nets["random init"]
+    L, R = smooth_pair(24, 40, 1)
+    a, _ = net.features_pair_hwc_split(L.cuda(), R.cuda())
+    with torch.no_grad():
+        net.weights[2].mul_(1.5)
+    b, _ = net.features_pair_hwc_split(L.cuda(), R.cuda())
+    ref = features_float64(net, L)
+    assert float((b.double().cpu() - ref).abs().max()) <= 2e-6
+    assert not torch.equal(a, b)
+    with torch.no_grad():
+        net.weights[2].div_(1.5)
+
+
+def test_whole_pair_with_split_features_matches_library_features(sd, nets):
+    """cfg1-sized pair through the whole timed region, fast stage variants, the two feature paths side by side:
+    feature differences of ~1e-6 may flip a WTA tie here and there; nothing else may move."""
+    import _hipabi as hip
+    import synthetic
+    H, W, D = 128, 192, 48
+    L, R, _, _, _ = synthetic.make_pair(H, W, D, seed=5)
+    net = nets["converted reference checkpoint"]
+    outs = {}
+    for feat in ("miopen", "split_f16"):
+        m = sd.StereoMatcher(net, cv_mode=hip.MCCNN_CV_MFMA, cbca_order=hip.MCCNN_CBCA_SEPARABLE, features=feat)
+        keep = {}
+        out = m.match(dev(L[:, :, 0]), dev(R[:, :, 0]), D, keep=keep)
+        outs[feat] = (out.cpu().numpy(), keep["wta"][0].cpu().numpy())
+    flips = float((outs["miopen"][1] != outs["split_f16"][1]).mean())
+    close = float(np.isclose(outs["miopen"][0], outs["split_f16"][0], atol=1e-3, equal_nan=True).mean())
+    assert flips <= 0.002, "%.4f of the WTA picks differ" % flips
+    assert close >= 0.99, "only %.4f of the final map within 1e-3 px" % close

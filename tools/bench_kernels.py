@@ -98,6 +98,21 @@ def main():
     add("cost_volume_exact", lambda: sd.cost_volume(fl, fr, D, hip.MCCNN_CV_EXACT, out=(va, vb)), 2 * vol_bytes)
     add("cost_volume_mfma", lambda: sd.cost_volume(fl, fr, D, hip.MCCNN_CV_MFMA, out=(va, vb)), 2 * vol_bytes)
 
+    # feature stack: both views; "bytes" = the activations each of the four 64 -> 64 layers reads and writes once
+    from model import NET
+    net = NET(None, input_patch_size=11, batch_size=1, device="cuda", seed=0)
+    act_bytes = 4 * 2 * 2.0 * H * W * 256
+    add("features_miopen", lambda: net.features_pair_hwc(dl, dr), act_bytes)
+    add("features_split", lambda: net.features_pair_hwc_split(dl, dr), act_bytes)
+    if not only or "conv3x3_split" in only:
+        x = sd.conv1_split(torch.stack((dl, dr)).contiguous(), net.weights[0].detach().contiguous(),
+                           net.biases[0].detach(), 5)
+        pk, ws = sd.conv3x3_split_pack(net.weights[1])
+        ms = timeit(lambda: sd.conv3x3_split(x, pk, ws, net.biases[1].detach(), last=False), args.iters)
+        flop = 2.0 * 2 * (H + 6) * (W + 6) * 64 * 64 * 9
+        print("%-22s %8.4f ms  %8.1f TFLOP/s float32-equivalent, %6.1f TFLOP/s f16 MFMA issued (3 products, of 2500)"
+              % ("conv3x3_split", ms, flop / ms / 1e9, 3 * flop / ms / 1e9), flush=True)
+
 
 if __name__ == "__main__":
     main()
