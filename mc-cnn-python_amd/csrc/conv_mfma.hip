@@ -70,6 +70,19 @@ __device__ __forceinline__ void split4(const float y[4], float scale, w2 &hi, w2
     lo = __builtin_bit_cast(w2, b);
 }
 
+__device__ __forceinline__ void split4_scaled(const float v[4], w2 &hi, w2 &lo)   // values already scaled and clamped
+{
+    h4 a, b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const _Float16 h = (_Float16)v[j];
+        a[j] = h;
+        b[j] = (_Float16)(v[j] - (float)h);
+    }
+    hi = __builtin_bit_cast(w2, a);
+    lo = __builtin_bit_cast(w2, b);
+}
+
 // weights [64 out][64 in][3][3] float32 (torch layout) -> fragment order:
 // [ks = q*9 + tap][part: hi, lo][map block mb][lane][8 x f16], lane: out = 32 mb + (lane & 31), in = 16 q + 8 (lane >> 5) + j
 __global__ __launch_bounds__(256) void conv3x3_split_pack_kernel(const float *__restrict__ w, float scale,
@@ -94,13 +107,13 @@ __global__ __launch_bounds__(256) void conv3x3_split_pack_kernel(const float *__
 }
 
 // Layer 1 (1 -> 64 maps) on the zero-padded image (process_functional.py:20-25), bias, ReLU, written as split records.
-// Thread = (pixel, channel group of 16): the same float32 multiply-adds as mccnn_conv1_pad_bias_relu, then the split.
+// Thread = one output pixel looping over the maps (weights and bias indexed uniformly: scalar loads), the same float32
+// multiply-adds as mccnn_conv1_pad_bias_relu, then the split; a lane writes its pixel's record in 16-byte pieces.
 __global__ __launch_bounds__(256) void conv1_split_kernel(const float *__restrict__ img, const float *__restrict__ w,
                                                           const float *__restrict__ bias, char *__restrict__ out, int H,
                                                           int W, int pad, int Ho, int Wo, float act_scale)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int q = t & 3, xo = t >> 2;
+    const int xo = blockIdx.x * 256 + threadIdx.x;
     const int yo = blockIdx.y, n = blockIdx.z;
     if (xo >= Wo) return;
     float v[9];
@@ -111,24 +124,36 @@ __global__ __launch_bounds__(256) void conv1_split_kernel(const float *__restric
             const int y = yo + i - pad, x = xo + j - pad;
             v[i * 3 + j] = (y >= 0 && y < H && x >= 0 && x < W) ? img[((size_t)n * H + y) * W + x] : 0.f;
         }
-    char *rec = out + (((size_t)n * Ho + yo) * Wo + xo) * cs::REC + q * 64;
+    char *rec = out + (((size_t)n * Ho + yo) * Wo + xo) * cs::REC;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        float y[4];
+    for (int q = 0; q < 4; ++q) {
+        w2 hi[4], lo[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = 16 * q + 4 * g + j;
-            float acc = 0.f;
+        for (int g = 0; g < 4; ++g) {
+            float y[4];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) acc += w[c * 9 + k] * v[k];
-            acc += bias[c];
-            y[j] = fmaxf(acc, 0.f);
+            for (int j = 0; j < 4; ++j) {
+                const int c = 16 * q + 4 * g + j;
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc += w[c * 9 + k] * v[k];
+                acc += bias[c];
+                y[j] = fmaxf(acc, 0.f);
+            }
+            split4(y, act_scale, hi[g], lo[g]);
         }
-        w2 hi, lo;
-        split4(y, act_scale, hi, lo);
-        *reinterpret_cast<w2 *>(rec + 8 * g) = hi;
-        *reinterpret_cast<w2 *>(rec + 32 + 8 * g) = lo;
+        w4 *p = reinterpret_cast<w4 *>(rec + q * 64);
+        p[0] = w4{hi[0].x, hi[0].y, hi[1].x, hi[1].y};
+        p[1] = w4{hi[2].x, hi[2].y, hi[3].x, hi[3].y};
+        p[2] = w4{lo[0].x, lo[0].y, lo[1].x, lo[1].y};
+        p[3] = w4{lo[2].x, lo[2].y, lo[3].x, lo[3].y};
     }
+}
+
+__device__ __forceinline__ void pin_loads()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0x78f);
 }
 
 // MODE 0: bias + ReLU, split records out.  MODE 1: bias, L2 normalisation over the 64 maps, float32 [N][Ho][Wo][64] out.
@@ -179,6 +204,9 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
     w4 st[NST];
     auto fetch = [&](int n, int ty0, int tx0, int q) {
         const int so = ((n * Hi + ty0) * Wi + tx0) * REC + q * 64;     // wave-uniform
+#ifdef CONV_ABL_NOSTAGE   // timing experiment: no activation loads (the LDS tile keeps whatever it holds)
+        if (so == 0x7fffffff)
+#endif
 #pragma unroll
         for (int r = 0; r < NST; ++r) st[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, goff[r], so, 0);
     };
@@ -197,16 +225,18 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
     commit(0);
     __syncthreads();
 
-    // A fragments: slot ks % 3, fetched two K steps ahead (the weights are the same for every tile, so the stream
-    // simply wraps)
-    w4 af[3][4];
+    // A fragments: slot ks % NSLOT, fetched NSLOT - 1 K steps ahead (the weights are the same for every tile, so the
+    // stream simply wraps).  vmcnt counts in order: the activation pieces fetched at the start of a channel group
+    // have to land before the first A fragment issued after them is needed, i.e. within NSLOT - 1 K steps.
+    constexpr int NSLOT = 4;
+    w4 af[NSLOT][4];
     auto fetch_a = [&](int slot, int ks) {
 #pragma unroll
         for (int f = 0; f < 4; ++f)
             af[slot][f] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16, (ks * 4 + f) * WFRAG, 0);
     };
-    fetch_a(0, 0);
-    fetch_a(1, 1);
+#pragma unroll
+    for (int i = 0; i < NSLOT - 1; ++i) fetch_a(i, i);
 
     const int bfrag = (wave * 4 * IW + (lane & 31)) * SLOT + 16 * (lane >> 5);
     char *const epi = lds + 2 * QBUF + wave * EPI;
@@ -222,29 +252,51 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
         const int vn = v + gridDim.x;
         int nn = 0, nty0 = 0, ntx0 = 0;
         if (vn < total) tile_base(vn, nn, nty0, ntx0);
-#pragma unroll 1
+        if (vn >= total) {       // last tile: the prefetch of "the next tile" re-reads this one (never used) - the
+            nn = n;              // loads stay unconditional, so the compiler's vmcnt counts stay exact
+            nty0 = ty0;
+            ntx0 = tx0;
+        }
+#pragma unroll
         for (int q = 0; q < 4; ++q) {
             // next channel group of this tile, or group 0 of the next tile, into registers
             if (q < 3)
                 fetch(n, ty0, tx0, q + 1);
-            else if (vn < total)
+            else
                 fetch(nn, nty0, ntx0, 0);
+            // Loads stay where they are written: without the compiler-level memory barrier instruction selection
+            // places these (unchained, read-only) loads next to their first use, and without the scheduling barrier
+            // (vector-memory instructions may not cross, everything else may) the scheduler sinks them there - either
+            // way the prefetch is gone.
+            pin_loads();
             const char *bq = lds + (q & 1) * QBUF + bfrag;
+            char *const other = lds + ((q + 1) & 1) * QBUF;
+            // B fragments one step (= one row of 32 pixels at one tap, 6 MFMAs) ahead: the wave issues in order, so a
+            // fragment read right before its MFMAs waits out the LDS latency with at most two MFMAs in the pipe
+            w4 bf[2][2];
+            auto read_b = [&](int slot, int step) {
+                const int tap = step >> 2, nb = step & 3;
+                const int dy = tap / 3, dx = tap - dy * 3;
+                const char *pb = bq + ((nb + dy) * IW + dx) * SLOT;
+                bf[slot][0] = *reinterpret_cast<const w4 *>(pb);
+                bf[slot][1] = *reinterpret_cast<const w4 *>(pb + 32);
+            };
+            read_b(0, 0);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int ks = q * 9 + tap;
-                int ks2 = ks + 2;
-                ks2 = ks2 >= 36 ? ks2 - 36 : ks2;
-                fetch_a((tap + 2) % 3, ks2);
-                const int slot = tap % 3;
-                const int dy = tap / 3, dx = tap - dy * 3;
+                fetch_a((ks + NSLOT - 1) % NSLOT, (ks + NSLOT - 1) % 36);
+                pin_loads();
+                const int slot = ks % NSLOT;
                 const h8 a_hi0 = __builtin_bit_cast(h8, af[slot][0]), a_hi1 = __builtin_bit_cast(h8, af[slot][1]);
                 const h8 a_lo0 = __builtin_bit_cast(h8, af[slot][2]), a_lo1 = __builtin_bit_cast(h8, af[slot][3]);
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) {
-                    const char *pb = bq + ((nb + dy) * IW + dx) * SLOT;
-                    const h8 b_hi = __builtin_bit_cast(h8, *reinterpret_cast<const w4 *>(pb));
-                    const h8 b_lo = __builtin_bit_cast(h8, *reinterpret_cast<const w4 *>(pb + 32));
+                    const int step = tap * 4 + nb;
+                    if (step + 1 < 36) read_b((step + 1) & 1, step + 1);
+                    __builtin_amdgcn_sched_barrier(0);   // the reads above are issued before the MFMAs below
+                    const h8 b_hi = __builtin_bit_cast(h8, bf[step & 1][0]);
+                    const h8 b_lo = __builtin_bit_cast(h8, bf[step & 1][1]);
                     acc[nb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo0, b_hi, acc[nb][0], 0, 0, 0);
                     acc[nb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo1, b_hi, acc[nb][1], 0, 0, 0);
                     acc[nb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi0, b_lo, acc[nb][0], 0, 0, 0);
@@ -252,25 +304,51 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
                     acc[nb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi0, b_hi, acc[nb][0], 0, 0, 0);
                     acc[nb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi1, b_hi, acc[nb][1], 0, 0, 0);
                 }
+                // the pieces fetched at the start of this group go to the other buffer two per tap from tap 4 on (they
+                // have landed: the A fragment waits since tap 3 are behind them in the in-order vmcnt queue), so the
+                // LDS writes run under the MFMAs instead of in front of the barrier
+                if (tap >= 9 - NST / 2) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int r = 2 * (tap - (9 - NST / 2)) + j;
+                        if (r < NST - 1 || last_piece) *reinterpret_cast<w4 *>(other + loff[r]) = st[r];
+                    }
+                }
             }
-            if (q < 3 || vn < total) commit((q + 1) & 1);
             __syncthreads();
         }
 
         // ---- epilogue: this wave's four rows of 32 pixels ----
         const int px = lane & 31, half = lane >> 5;
+#ifdef CONV_ABL_NOEPI   // timing experiment: one store per accumulator so the MFMAs stay live
+        {
+            float t = 0.f;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t += acc[nb][mb][r];
+            if (t == 123.456f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t), rs_out, lane * 4, 0, 0);
+        }
+#else
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-            float y[2][16];
+            float y[2][16];      // MODE 0: relu(x) * act_scale, clamped to the f16 range; MODE 1: x
             float ss = 0.f;
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ch = 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const float t = acc[nb][mb][r] * inv_scale + bias[ch];
-                    y[mb][r] = MODE == 0 ? fmaxf(t, 0.f) : t;
-                    if (MODE == 1) ss = fmaf(t, t, ss);
+                    if (MODE == 0) {
+                        const float t = fmaf(acc[nb][mb][r], inv_scale * act_scale, bias[ch] * act_scale);
+                        y[mb][r] = __builtin_amdgcn_fmed3f(t, 0.f, 65504.f);
+                    } else {
+                        const float t = fmaf(acc[nb][mb][r], inv_scale, bias[ch]);
+                        y[mb][r] = t;
+                        ss = fmaf(t, t, ss);
+                    }
                 }
             float nrm = 1.f;
             if (MODE == 1) {
@@ -285,7 +363,7 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
                     const int ch = 32 * mb + 8 * g + 4 * half;          // first of 4 consecutive maps
                     if (MODE == 0) {
                         w2 hi, lo;
-                        split4(&y[mb][4 * g], act_scale, hi, lo);
+                        split4_scaled(&y[mb][4 * g], hi, lo);
                         char *p = epi + px * EPITCH + (ch >> 4) * 64 + (ch & 15) * 2;
                         *reinterpret_cast<w2 *>(p) = hi;
                         *reinterpret_cast<w2 *>(p + 32) = lo;
@@ -310,6 +388,7 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
             }
             __builtin_amdgcn_wave_barrier();
         }
+#endif
         if (vn >= total) break;
         v = vn;
         n = nn;
@@ -342,7 +421,7 @@ extern "C" int mccnn_conv1_split(const float *images, const float *weights, cons
     const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
     MCCNN_REQUIRE(Ho > 0 && Wo > 0 && Ho <= 65535 && N <= 65535, MCCNN_E_UNSUPPORTED,
                   "mccnn_conv1_split: output %dx%d outside the grid", Wo, Ho);
-    hipLaunchKernelGGL(conv1_split_kernel, dim3(cdiv(4L * Wo, 256), Ho, N), dim3(256), 0, (hipStream_t)stream, images,
+    hipLaunchKernelGGL(conv1_split_kernel, dim3(cdiv(Wo, 256), Ho, N), dim3(256), 0, (hipStream_t)stream, images,
                        weights, bias, reinterpret_cast<char *>(out), H, W, pad, Ho, Wo, act_scale);
     return check_launch("mccnn_conv1_split");
 }

@@ -107,8 +107,14 @@ def main():
     if not only or "conv3x3_split" in only:
         x = sd.conv1_split(torch.stack((dl, dr)).contiguous(), net.weights[0].detach().contiguous(),
                            net.biases[0].detach(), 5)
+        pair = torch.stack((dl, dr)).contiguous()
+        ms = timeit(lambda: sd.conv1_split(pair, net.weights[0].detach().contiguous(), net.biases[0].detach(), 5),
+                    args.iters)
+        print("%-22s %8.4f ms" % ("conv1_split", ms), flush=True)
         pk, ws = sd.conv3x3_split_pack(net.weights[1])
         ms = timeit(lambda: sd.conv3x3_split(x, pk, ws, net.biases[1].detach(), last=False), args.iters)
+        ms_last = timeit(lambda: sd.conv3x3_split(x, pk, ws, net.biases[1].detach(), last=True), args.iters)
+        print("%-22s %8.4f ms" % ("conv3x3_split(last)", ms_last), flush=True)
         flop = 2.0 * 2 * (H + 6) * (W + 6) * 64 * 64 * 9
         print("%-22s %8.4f ms  %8.1f TFLOP/s float32-equivalent, %6.1f TFLOP/s f16 MFMA issued (3 products, of 2500)"
               % ("conv3x3_split", ms, flop / ms / 1e9, 3 * flop / ms / 1e9), flush=True)
