@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--exact", action="store_true",
                     help="bit-exact variants (NumPy-order cost volume, reference-order CBCA) instead of the fast ones")
+    ap.add_argument("--library-features", action="store_true",
+                    help="conv features through the float32 library convolutions (MIOpen) instead of the split-operand "
+                         "matrix-core kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch the ~75 kernels of a pair one by one instead of replaying the captured hipGraph")
@@ -164,7 +167,8 @@ def main():
     dr = torch.from_numpy(R[:, :, 0]).cuda()
     matcher = sd.StereoMatcher(
         net, cv_mode=hip.MCCNN_CV_EXACT if args.exact else hip.MCCNN_CV_MFMA,
-        cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER if args.exact else hip.MCCNN_CBCA_SEPARABLE)
+        cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER if args.exact else hip.MCCNN_CBCA_SEPARABLE,
+        features="miopen" if (args.exact or args.library_features) else "split_f16")
 
     use_graph = not args.no_graph
     if use_graph:
@@ -206,6 +210,17 @@ def main():
         matcher.match(dl, dr, D)
     torch.cuda.synchronize()
     eager_ms = (time.perf_counter() - t1) / nside * 1e3
+    lib_ms = None
+    if matcher.features != "miopen":             # the same pair with the float32 library convolutions, for reference
+        mlib = sd.StereoMatcher(net, cv_mode=matcher.cv_mode, cbca_order=matcher.cbca_order, features="miopen")
+        mlib._ws = matcher._ws                   # same shape: shares the resident workspace
+        mlib.match(dl, dr, D)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for _ in range(nside):
+            mlib.match(dl, dr, D)
+        torch.cuda.synchronize()
+        lib_ms = (time.perf_counter() - t3) / nside * 1e3
     hl, hr = torch.from_numpy(L[:, :, 0].copy()).pin_memory(), torch.from_numpy(R[:, :, 0].copy()).pin_memory()
     t2 = time.perf_counter()                     # match.py's own region: host images in, host map out
     for _ in range(nside):
@@ -249,6 +264,9 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %dx%d synthetic stereo pair, D=%d, one pair per GPU" % (args.config, W, H, D),
                    "variant": "exact" if args.exact else "fast (MFMA cost volume, separable CBCA)",
+                   "features": "float32 library convolutions (MIOpen)" if (args.exact or args.library_features) else
+                   "split-operand f16 MFMA convolutions (float32 in/out, 3 products per multiply, float32 accumulate; "
+                   "measured 5e-7 from a float64 evaluation vs 2.5e-7 for the library path: profiles/parity_features_split_r02.json)",
                    "launch": "one hipGraph replay per pair" if use_graph else "kernel by kernel",
                    "weights": "converted reference checkpoint" if os.path.isfile(wpath) else "random init"},
         "roofline": dict(rooflines[dominant], kernel=dominant) if dominant else None,
@@ -267,6 +285,7 @@ def main():
         # and match.py's own timed region, host images in / host map out over PCIe (pinned buffers)
         "ms_per_step_kernel_by_kernel": round(eager_ms, 3),
         "ms_per_step_host_in_host_out": round(host_io_ms, 3),
+        "ms_per_step_library_features_kernel_by_kernel": round(lib_ms, 3) if lib_ms is not None else None,
         "sum_of_stage_ms": round(sum(per_step.values()), 3),
         "process_group": (torch.distributed.get_backend() + " x%d" % torch.distributed.get_world_size())
         if torch.distributed.is_initialized() else None,

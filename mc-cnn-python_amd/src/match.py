@@ -9,9 +9,11 @@ im1.png + calib.txt beside it, standardises both views, runs the timed region (f
 exactly where the reference does (match.py:99-110, 182-184).
 
 By default every stage after the conv features is bit-identical to the reference's NumPy code on the same inputs.
-Addition: --fast selects the tolerance-bounded variants of the two stages that have one (cost volume on the matrix
-cores instead of NumPy's summation order, <= 2e-6; CBCA through float64 prefix sums instead of the reference's list
-order, <= 1e-6 per iteration) - about 10x faster; near-ties in the WTA can then resolve differently.
+Addition: --fast selects the tolerance-bounded variants of the stages that have one (conv features on the matrix
+cores with split f16 operands instead of the float32 library convolutions, ~5e-7 from a float64 evaluation; cost
+volume on the matrix cores instead of NumPy's summation order, <= 2e-6; CBCA through float64 prefix sums instead of
+the reference's list order, <= 1e-6 per iteration) - about 13x faster; near-ties in the WTA can then resolve
+differently.
 Multi-GPU: launch one process per GPU with different -g / -s / -e, as the reference intends (match.py:17, 26-28),
 or use `torchrun --nproc-per-node N match.py ...`: rank r then takes the pairs i = r (mod N) of the window.
 """
@@ -57,8 +59,8 @@ parser.add_argument("--blur_sigma", type=float, default=6, help="bilateral filte
 parser.add_argument("--blur_threshold", type=float, default=2, help="bilateral filter: intensity gate")
 # additions of this implementation
 parser.add_argument("--fast", action="store_true",
-                    help="use the tolerance-bounded fast variants of two stages (cost volume on the matrix cores, "
-                         "<= 2e-6; CBCA through float64 prefix sums, <= 1e-6 per iteration) - about 10x faster.  "
+                    help="use the tolerance-bounded fast variants (conv features and cost volume on the matrix cores, "
+                         "<= 2e-6; CBCA through float64 prefix sums, <= 1e-6 per iteration) - about 13x faster.  "
                          "Without it every stage after the conv features is bit-identical to the reference's NumPy code")
 parser.add_argument("--exact", action="store_true", help="(default; kept for compatibility) the bit-exact variants")
 # opt-in departures from the reference's results: what the MC-CNN paper does and the reference names but leaves out
@@ -133,6 +135,7 @@ def main(argv=None):
         net, hyper_parameters(args),
         cv_mode=hip.MCCNN_CV_MFMA if args.fast else hip.MCCNN_CV_EXACT,
         cbca_order=hip.MCCNN_CBCA_SEPARABLE if args.fast else hip.MCCNN_CBCA_REFERENCE_ORDER,
+        features="split_f16" if args.fast and args.patch_size >= 5 else "miopen",
         extras=dict(both_view_support=args.paper_support_regions,
                     interpolation_directions=16 if args.paper_interpolation else 4,
                     occlusion_from_left=args.paper_interpolation, numpy1_promotion=args.numpy1_promotion))
