@@ -52,8 +52,9 @@ const char *mccnn_last_error_string(void);
  * lcv[d,h,w] = -<fl[h,w,:], fr[h,w-d,:]> for w >= d, border columns filled by the reference's 3-tap mean
  * recurrences, rcv[d,h,w] = lcv[d,h,w+d] (+ its own border recurrence).  Requires 1 <= D <= W-2.
  * mode MCCNN_CV_EXACT reproduces NumPy's pairwise float32 summation order bit for bit (C must be 64);
- * mode MCCNN_CV_MFMA contracts the 64 channels on the matrix cores (v_mfma_f32_32x32x2_f32, fma-chain order,
- * |diff| <= 2e-6 on unit-norm features). */
+ * mode MCCNN_CV_MFMA contracts the 64 channels on the matrix cores (every float32 operand as two f16 numbers, three
+ * v_mfma_f32_32x32x16_f16 products per K step, float32 accumulation): |diff| <= 2e-6 on unit-norm features - the
+ * features must be unit vectors (|x| <= 1), as NET produces them. */
 #define MCCNN_CV_EXACT 0
 #define MCCNN_CV_MFMA 1
 int mccnn_cost_volume(const float *fl, const float *fr, int H, int W, int C, int D, float *lcv, float *rcv, int mode,

@@ -22,6 +22,9 @@ namespace mccnn {
 constexpr int CV_TW = 64;   // output columns per workgroup
 constexpr int CV_DT = 64;   // disparities per workgroup
 constexpr int CV_C = 64;    // feature channels (NET num_conv_feature_maps)
+#ifndef CVM_WAVES_PER_SIMD
+#define CVM_WAVES_PER_SIMD 6
+#endif
 constexpr int CV_LD = 68;   // padded LDS row (floats): 16-B slot index = (row + c4) mod 16 -> conflict-free b128
 
 __global__ __launch_bounds__(256) void cost_volume_exact_kernel(const float *__restrict__ fl,
@@ -92,23 +95,51 @@ __global__ __launch_bounds__(256) void cost_volume_exact_kernel(const float *__r
 }
 
 // ---- MFMA variant ---------------------------------------------------------------------------------------------
-// One wave computes a 32(w) x 32(w') block of S with 32 x v_mfma_f32_32x32x2_f32 (K = 64 channels, 2 per issue).
-// A operand: lane l holds fl[w = l&31][k = l>>5]; B operand: fr[w' = l&31][k = l>>5]; C/D: col = lane&31 (w'),
-// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (w).  A workgroup of 4 waves covers 64 w x 64 w' and keeps only the
-// band 0 <= w-w' < D.  The accumulator is staged through LDS so that stores run along w for fixed d.
+// One wave computes a 32(w) x 32(w') block of S = <fl[w], fr[w']>; a workgroup of 4 waves covers 64 w x 64 w' and
+// keeps only the band 0 <= w-w' < D.  A/B operands: lane l holds pixel l&31, channels 8 (l>>5) .. +7 of a 16-channel
+// K step; C/D: col = lane&31 (w'), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (w).
+//
+// What bounds this kernel is neither the matrix cores nor the store pattern but how many workgroups a CU can hold:
+// a workgroup is a chain of latencies (operand fetch, LDS staging, products, the transposition through LDS, and
+// above all the drain of its stores before its LDS can be handed on), and the first version - float32-input MFMA,
+// 34.5 KiB of LDS, 4 workgroups per CU - took the same 0.32 ms whether its 2048 matrix-core cycles per block were cut
+// to 384, or its stores were rearranged into whole 512-byte runs (a 128 x 64 output-stationary tiling, 1.5 x the
+// products, 121 KiB of LDS: 0.40 ms).  So this version is built for a small footprint instead:
+//   * operands as two f16 numbers each (x * 2^10 = hi + lo; unit vectors, 22 significand bits), three
+//     v_mfma_f32_32x32x16_f16 products per K step (hi*hi + hi*lo + lo*hi), float32 accumulation: <= 3e-7 from the exact
+//     dot product, 384 matrix-core cycles per block;
+//   * the 64 channels staged in two halves (18 KiB for both operand tiles; the second half waits in registers);
+//   * the product tile T diagonal-major but folded: diagonal dd >= 0 (columns dd..63) and diagonal dd - 64 (columns
+//     0..dd-1) share row dd of T[64][68] - 17 KiB instead of 34 - and the quads that straddle the fold are the ragged
+//     ends of both diagonals, written element by element.
+// 18 KiB of LDS: 8 workgroups per CU.  The accumulator is staged through LDS so that stores run along w for fixed d.
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-constexpr int CVM_PL = 65;  // LDS pitch of the operand tiles: bank = (row + k) mod 32 -> conflict-free ds_read_b32
-constexpr int CVM_TP = 68;  // LDS pitch of the diagonal-major product tile T[w-x+63][w] (floats, 16-byte rows)
+typedef _Float16 cv_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 cv_h4 __attribute__((ext_vector_type(4)));
+constexpr int CVM_SP = 144;  // LDS bytes per operand pixel and channel half: [K step][hi 32 B | lo 32 B] + 16 pad
+constexpr int CVM_TP = 68;   // LDS pitch of the folded product tile T[(w-x) & 63][w] (floats, 16-byte rows)
 
-__global__ __launch_bounds__(256) void cost_volume_mfma_kernel(const float *__restrict__ fl,
-                                                               const float *__restrict__ fr, int H, int W, int D,
-                                                               float *__restrict__ lcv, float *__restrict__ rcv,
-                                                               int nwt, int nbands, int total)
+__device__ __forceinline__ void cv_split4(const float4 v, cv_h4 &hi, cv_h4 &lo)
 {
-    // operand tiles and, after the products are done, the diagonal-major product tile share one allocation
-    constexpr int LDS_FLOATS = (2 * 64 * CVM_PL > 127 * CVM_TP) ? 2 * 64 * CVM_PL : 127 * CVM_TP;
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-    float *sL = lds, *sR = lds + 64 * CVM_PL, *sT = lds;
+    const float x[4] = {v.x * 1024.f, v.y * 1024.f, v.z * 1024.f, v.w * 1024.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const _Float16 h = (_Float16)x[j];
+        hi[j] = h;
+        lo[j] = (_Float16)(x[j] - (float)h);
+    }
+}
+
+__global__ __launch_bounds__(256, CVM_WAVES_PER_SIMD) void cost_volume_mfma_kernel(
+    const float *__restrict__ fl, const float *__restrict__ fr, int H, int W, int D, float *__restrict__ lcv,
+    float *__restrict__ rcv, int nwt, int nbands, int total)
+{
+    // operand tiles (one channel half at a time) and, after the products are done, the folded product tile share one
+    // allocation
+    constexpr int LDS_BYTES = (2 * 64 * CVM_SP > 64 * CVM_TP * 4) ? 2 * 64 * CVM_SP : 64 * CVM_TP * 4;
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    char *oL = lds, *oR = lds + 64 * CVM_SP;
+    float *sT = reinterpret_cast<float *>(lds);
     // tile (bw, bx): left columns w0..w0+63, right columns x0..x0+63; d = w - x in (w0-x0-63 .. w0-x0+63)
     // Work order.  The pieces of one 128-byte line of a volume row come from neighbouring tiles (the next w tile, the
     // next band), and the dispatcher deals consecutive workgroups to the 8 XCDs round-robin - with the plain grid
@@ -128,94 +159,107 @@ __global__ __launch_bounds__(256) void cost_volume_mfma_kernel(const float *__re
     if (w0 - x0 - 63 >= D) return;
     const int tid = threadIdx.x;
     const size_t rowbase = (size_t)h * W;
-    for (int i = tid; i < 64 * 16; i += 256) {
-        const int px = i >> 4, c4 = i & 15;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f), u = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (w0 + px < W) v = *reinterpret_cast<const float4 *>(fl + (rowbase + w0 + px) * CV_C + c4 * 4);
-        const int x = x0 + px;
-        if (x >= 0 && x < W) u = *reinterpret_cast<const float4 *>(fr + (rowbase + x) * CV_C + c4 * 4);
-        float *dl = &sL[px * CVM_PL + c4 * 4], *dr = &sR[px * CVM_PL + c4 * 4];
-        dl[0] = v.x; dl[1] = v.y; dl[2] = v.z; dl[3] = v.w;
-        dr[0] = u.x; dr[1] = u.y; dr[2] = u.z; dr[3] = u.w;
-    }
-    __syncthreads();
+    // piece p = j*256 + tid of a channel half: pixel p >> 3, channels 4 (p & 7) .. + 3 of the half
+    float4 vl[2][2], vr[2][2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int p = j * 256 + tid, px = p >> 3, c4 = hf * 8 + (p & 7);
+            vl[hf][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            vr[hf][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (w0 + px < W) vl[hf][j] = *reinterpret_cast<const float4 *>(fl + (rowbase + w0 + px) * CV_C + c4 * 4);
+            const int x = x0 + px;
+            if (x >= 0 && x < W) vr[hf][j] = *reinterpret_cast<const float4 *>(fr + (rowbase + x) * CV_C + c4 * 4);
+        }
     const int wave = tid >> 6, lane = tid & 63;
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;  // this wave's 32x32 sub-block (w rows, x cols)
-    f32x16 acc;
+    f32x16 acc, acc2;                                       // hi*hi, and the two cross terms
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const float *pa = &sL[(wr + (lane & 31)) * CVM_PL + (lane >> 5)];
-    const float *pb = &sR[(wc + (lane & 31)) * CVM_PL + (lane >> 5)];
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f, acc2[i] = 0.f;
+    const char *pa = oL + (wr + (lane & 31)) * CVM_SP + 16 * (lane >> 5);
+    const char *pb = oR + (wc + (lane & 31)) * CVM_SP + 16 * (lane >> 5);
 #pragma unroll
-    for (int k = 0; k < CV_C; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k], pb[k], acc, 0, 0, 0);
+    for (int hf = 0; hf < 2; ++hf) {
+        if (hf) __syncthreads();   // everyone is done with the first half's tiles
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int p = j * 256 + tid, px = p >> 3, c = p & 7;
+            const int off = px * CVM_SP + (c >> 2) * 64 + (c & 3) * 8;
+            cv_h4 hh, ll;
+            cv_split4(vl[hf][j], hh, ll);
+            *reinterpret_cast<cv_h4 *>(oL + off) = hh;
+            *reinterpret_cast<cv_h4 *>(oL + off + 32) = ll;
+            cv_split4(vr[hf][j], hh, ll);
+            *reinterpret_cast<cv_h4 *>(oR + off) = hh;
+            *reinterpret_cast<cv_h4 *>(oR + off + 32) = ll;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const cv_h8 a_hi = *reinterpret_cast<const cv_h8 *>(pa + q * 64);
+            const cv_h8 a_lo = *reinterpret_cast<const cv_h8 *>(pa + q * 64 + 32);
+            const cv_h8 b_hi = *reinterpret_cast<const cv_h8 *>(pb + q * 64);
+            const cv_h8 b_lo = *reinterpret_cast<const cv_h8 *>(pb + q * 64 + 32);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc2, 0, 0, 0);
+        }
+    }
     __syncthreads();   // every wave is done with the operand tiles: their LDS becomes the product tile
-    // Products go to LDS diagonal-major, already negated: T[w - x + 63][w].  A row of T is one disparity d = dbase +
-    // (row - 63) and runs along w, which is how both volumes are written (lcv[d][h][w] and rcv[d][h][w - d]).
+    // Products go to LDS diagonal-major and folded, already negated: T[(w - x) & 63][w] (w, x local).  A row of T
+    // holds diagonal dd = row in its columns row..63 and diagonal row - 64 in its columns 0..row-1; both run along
+    // w, which is how both volumes are written (lcv[d][h][w] and rcv[d][h][w - d]).
 #pragma unroll
     for (int rg = 0; rg < 16; ++rg) {
         const int row = wr + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
         const int col = wc + (lane & 31);
-        sT[(row - col + 63) * CVM_TP + row] = -1.f * acc[rg];
+        sT[((row - col) & 63) * CVM_TP + row] = (acc[rg] + acc2[rg]) * (-1.f / 1048576.f);
     }
     __syncthreads();
     const size_t plane = (size_t)H * W;
     const int dbase = w0 - x0;  // d of the main diagonal
-    // (1) whole quads: a lane stores 4 consecutive w of one diagonal (16 B, dword aligned) to both volumes - the
-    // vector-memory pipe costs about the same per wave instruction whatever its width; one instruction covers 4
-    // diagonals x 16 quads.  Quads cut by an end of the diagonal (the tile border in x) are left to pass (2), so
-    // this loop has no per-element path except at the right image border.
+    // A lane stores 4 consecutive w of one diagonal (16 B, dword aligned) to both volumes - the vector-memory pipe
+    // costs about the same per wave instruction whatever its width; one instruction covers 4 rows of T x 16 quads.
+    // The quad of a row that straddles the fold holds the last elements of one diagonal and the first of the other:
+    // element by element.
     typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
     const int q = lane & 15, sub = lane >> 4;
-    for (int dg = wave; dg < 32; dg += 4) {
-        const int diag = dg * 4 + sub;
-        const int dd = diag - 63;      // w_local - x_local
-        const int d = dbase + dd;
+    for (int rgp = wave; rgp < 16; rgp += 4) {
+        const int row = rgp * 4 + sub;
         const int wl = 4 * q;          // first w_local of this lane's quad
-        const int xl = wl - dd;        // matching x_local
-        const int w = w0 + wl, x = x0 + xl;
-        if (diag >= 127 || d < 0 || d >= D || xl < 0 || xl + 3 > 63 || w >= W) continue;
-        const float4 t = *reinterpret_cast<const float4 *>(&sT[diag * CVM_TP + wl]);
-        float *pl = lcv + (size_t)d * plane + rowbase + w;
-        float *pr = rcv + (size_t)d * plane + rowbase + x;
-        if (w + 3 < W) {
-            f4u o;
-            o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
-            *reinterpret_cast<f4u *>(pl) = o;
-            *reinterpret_cast<f4u *>(pr) = o;
-        } else {
-            const float v[4] = {t.x, t.y, t.z, t.w};
+        const float4 t = *reinterpret_cast<const float4 *>(&sT[row * CVM_TP + wl]);
+        const float v[4] = {t.x, t.y, t.z, t.w};
+        const int w = w0 + wl;
+        if (wl >= row || wl + 3 < row) {
+            const int dd = wl >= row ? row : row - 64;
+            const int d = dbase + dd;
+            if (d < 0 || d >= D || w >= W) continue;
+            float *pl = lcv + (size_t)d * plane + rowbase + w;
+            float *pr = rcv + (size_t)d * plane + rowbase + (w - d);
+            if (w + 3 < W) {
+                f4u o;
+                o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+                *reinterpret_cast<f4u *>(pl) = o;
+                *reinterpret_cast<f4u *>(pr) = o;
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (w + j < W) {
-                    pl[j] = v[j];
-                    pr[j] = v[j];
-                }
-        }
-    }
-    // (2) the ragged end of each diagonal: at most 3 elements, at the end where the diagonal leaves the tile through
-    // x_local = 0 (dd > 0, its first elements) or x_local = 63 (dd < 0, its last elements)
-    for (int i = tid; i < 127 * 3; i += 256) {
-        const int diag = i / 3, j = i - diag * 3;
-        const int dd = diag - 63;
-        const int d = dbase + dd;
-        if (dd == 0 || d < 0 || d >= D) continue;
-        int wl;
-        if (dd > 0) {
-            const int r = dd & 3;              // the quad holding w_local = dd starts r elements earlier
-            if (r == 0 || j >= 4 - r) continue;
-            wl = dd + j;
+                for (int j = 0; j < 4; ++j)
+                    if (w + j < W) {
+                        pl[j] = v[j];
+                        pr[j] = v[j];
+                    }
+            }
         } else {
-            const int e = 63 + dd;             // last element of the diagonal
-            const int cnt = (e & 3) + 1;
-            if (cnt == 4 || j >= cnt) continue;
-            wl = e - j;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int d = dbase + (wl + j >= row ? row : row - 64);
+                if (d >= 0 && d < D && w + j < W) {
+                    lcv[(size_t)d * plane + rowbase + w + j] = v[j];
+                    rcv[(size_t)d * plane + rowbase + (w + j - d)] = v[j];
+                }
+            }
         }
-        const int xl = wl - dd;
-        const int w = w0 + wl, x = x0 + xl;
-        if (w >= W || x < 0) continue;
-        const float v = sT[diag * CVM_TP + wl];
-        lcv[(size_t)d * plane + rowbase + w] = v;
-        rcv[(size_t)d * plane + rowbase + x] = v;
     }
 }
 
