@@ -5,7 +5,7 @@
 Tolerances:
   bit-exact   cost volume (exact mode), arms/counts, CBCA (reference order), every SGM pass, WTA index, LR/interp,
               sub-pixel, median, bilateral
-  <= 2e-6     cost volume on the matrix cores (fma-chain order instead of NumPy's pairwise order)
+  <= 2e-6     cost volume on the matrix cores (split-f16 MFMA products instead of NumPy's pairwise order)
   <= 8 spacings of max|input| for one iteration, <= 2 per iteration over many - CBCA separable order (the correctly
               rounded mean against the reference's flat float32 running sum)
   <= 1e-5     features vs the float64-accumulating restatement (TensorFlow parity itself is unpinned)
@@ -335,6 +335,28 @@ def test_oracle_wta_ties_and_postprocessing(pf, H, W, D):
     assert_bits(pf.bilateral_filter(img, om, 5, 5, 0, 6, 2), o.bilateral_filter(img, om, 5, 5, 0, 6, 2), "bilateral")
     assert_bits(pf.bilateral_filter(img, om, 3, 5, 0, 2.5, 0.7), o.bilateral_filter(img, om, 3, 5, 0, 2.5, 0.7),
                 "bilateral 3x5")
+
+
+@pytest.mark.parametrize("H,W", [(5, 1), (3, 64), (17, 65), (40, 129), (33, 257), (70, 700), (9, 1030)])
+def test_oracle_interpolation_mask_kernels(pf, H, W):
+    """The bit-mask interpolation (column carries + row masks) against the oracle's literal walks: widths on either
+    side of the 64-pixel mask words and of the 256-thread row loop, rows and columns without any match, sparse and dense
+    matches, all three states."""
+    import oracle as o
+    D = 40
+    for dens, seed in ((0.5, 0), (0.03, 1), (0.97, 2)):
+        rng = np.random.default_rng(seed + H * W)
+        dl = rng.integers(0, D, size=(H, W)).astype(np.float32)
+        # dr chosen so that a fraction `dens` of the pixels passes the left-right check
+        dr = rng.integers(0, D, size=(H, W)).astype(np.float32)
+        ok = rng.random((H, W)) < dens
+        hh, ww = np.nonzero(ok)
+        tgt = ww - dl[hh, ww].astype(np.int64)
+        keep = tgt >= 0
+        dr[hh[keep], tgt[keep]] = dl[hh[keep], ww[keep]]
+        if H > 2:
+            dl[H // 2, :] = D + 5.0          # a row of occlusions (disparity out of range)
+        assert_bits(pf.interpolation(dl, dr, D), o.interpolation(dl, dr, D), "interpolation %dx%d %g" % (W, H, dens))
 
 
 def test_layout_round_trip(sd):
