@@ -82,6 +82,10 @@ size_t mccnn_support_bytes(int H, int W); /* whole buffer: all planes (0 for non
 #define MCCNN_SUPPORT_COUNT(s) ((s) >> 20)
 int mccnn_cross_arms(const float *image, int H, int W, float tau, int L, mccnn_support_t *support,
                      mccnn_stream_t stream);
+/* Both views in one call (compute_cross_region is called once per image right after each other, pf:120-121): the
+ * same results as two mccnn_cross_arms calls, half the launches. */
+int mccnn_cross_arms_pair(const float *image_left, const float *image_right, int H, int W, float tau, int L,
+                          mccnn_support_t *support_left, mccnn_support_t *support_right, mccnn_stream_t stream);
 int mccnn_cross_region_list(const mccnn_support_t *support, int H, int W, int L, int32_t *region,
                             mccnn_stream_t stream);
 

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(64) void cost_volume_fill_kernel(float *__restrict_
 {
     __shared__ float tile[64 * 65];
     const int lane = threadIdx.x;
-    const int d = blockIdx.y + 1;              // plane 0 has no border
+    const int d = D - 1 - blockIdx.y;          // plane 0 has no border; the longest recurrences start first
     const int h0 = blockIdx.x * 64;
     const int h = min(h0 + lane, H - 1);       // surplus lanes repeat the last row and store nothing
     const int nrows = min(64, H - h0);

@@ -38,12 +38,16 @@ __device__ __forceinline__ float norm1(float x)
     return sqrtf(sq);
 }
 
-__global__ __launch_bounds__(256) void cross_arms_kernel(const float *__restrict__ img, int H, int W, float tau, int L,
-                                                         Support *__restrict__ sup)
+// blockIdx.z selects the image (mccnn_cross_arms_pair: both views in one launch)
+__global__ __launch_bounds__(256) void cross_arms_kernel(const float *__restrict__ img0, const float *__restrict__ img1,
+                                                         int H, int W, float tau, int L, Support *__restrict__ sup0,
+                                                         Support *__restrict__ sup1)
 {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     const int h = blockIdx.y;
     if (w >= W) return;
+    const float *__restrict__ img = blockIdx.z ? img1 : img0;
+    Support *__restrict__ sup = blockIdx.z ? sup1 : sup0;
     const float cur = img[(size_t)h * W + w];
     int up = 0, down = 0, left = 0, right = 0;
     // pf:585-591 / 612-618: bias 0 is the anchor itself (|0| < tau); stop at the first failure
@@ -125,11 +129,13 @@ __host__ __device__ __forceinline__ size_t emit_plane_offset(int H, int W)
 // bits of the same word whose lower 20 bits (the arms, written by the previous kernel and never changed here) the
 // neighbours are reading: relaxed atomics make that formally race-free, and any mix of old/new words is correct.
 // The same kernel fills the derived planes of the support buffer (above).
-__global__ __launch_bounds__(256) void cross_count_kernel(Support *__restrict__ sup, int H, int W)
+__global__ __launch_bounds__(256) void cross_count_kernel(Support *__restrict__ sup0, Support *__restrict__ sup1, int H,
+                                                          int W)
 {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     const int h = blockIdx.y;
     if (w >= W) return;
+    Support *__restrict__ sup = blockIdx.z ? sup1 : sup0;
     auto ld = [&](size_t i) { return __hip_atomic_load(&sup[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     const size_t p = (size_t)h * W + w;
     const uint32_t a = ld(p);
@@ -766,6 +772,25 @@ static int check_support_record(const mccnn_support_t *support, int H, int W, in
     return 0;
 }
 
+static int launch_cross_arms(const float *img0, const float *img1, mccnn_support_t *sup0, mccnn_support_t *sup1, int n,
+                             int H, int W, float tau, int L, hipStream_t s)
+{
+    using namespace mccnn;
+    const dim3 grid(cdiv(W, 256), H, n), block(256);
+    hipLaunchKernelGGL(cross_arms_kernel, grid, block, 0, s, img0, img1, H, W, tau, L, sup0, sup1);
+    int rc = check_launch("mccnn_cross_arms");
+    if (rc) return rc;
+    hipLaunchKernelGGL(cross_count_kernel, grid, block, 0, s, sup0, sup1, H, W);
+    rc = check_launch("mccnn_cross_arms(count)");
+    if (rc == 0) {
+        std::lock_guard<std::mutex> lock(g_support_mu);
+        if (g_support.size() > 4096) g_support.clear();   // bounded: stale entries only cost a missed check
+        g_support[sup0] = SupportInfo{H, W, L};
+        g_support[sup1] = SupportInfo{H, W, L};
+    }
+    return rc;
+}
+
 extern "C" size_t mccnn_support_bytes(int H, int W)
 {
     if (H <= 0 || W <= 0) return 0;
@@ -780,19 +805,21 @@ extern "C" int mccnn_cross_arms(const float *image, int H, int W, float tau, int
     MCCNN_REQUIRE(H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_cross_arms: non-positive size");
     MCCNN_REQUIRE(L >= 1 && L <= 32, MCCNN_E_UNSUPPORTED,
                   "mccnn_cross_arms: L=%d outside [1,32] (5-bit arms, 12-bit region size)", L);
-    hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(cdiv(W, 256), H), block(256);
-    hipLaunchKernelGGL(cross_arms_kernel, grid, block, 0, s, image, H, W, tau, L, support);
-    int rc = check_launch("mccnn_cross_arms");
-    if (rc) return rc;
-    hipLaunchKernelGGL(cross_count_kernel, grid, block, 0, s, support, H, W);
-    rc = check_launch("mccnn_cross_arms(count)");
-    if (rc == 0) {
-        std::lock_guard<std::mutex> lock(g_support_mu);
-        if (g_support.size() > 4096) g_support.clear();   // bounded: stale entries only cost a missed check
-        g_support[support] = SupportInfo{H, W, L};
-    }
-    return rc;
+    return launch_cross_arms(image, image, support, support, 1, H, W, tau, L, (hipStream_t)stream);
+}
+
+extern "C" int mccnn_cross_arms_pair(const float *image_left, const float *image_right, int H, int W, float tau, int L,
+                                     mccnn_support_t *support_left, mccnn_support_t *support_right,
+                                     mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(image_left && image_right && support_left && support_right, MCCNN_E_INVALID,
+                  "mccnn_cross_arms_pair: null pointer");
+    MCCNN_REQUIRE(support_left != support_right, MCCNN_E_INVALID, "mccnn_cross_arms_pair: the two buffers must differ");
+    MCCNN_REQUIRE(H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_cross_arms_pair: non-positive size");
+    MCCNN_REQUIRE(L >= 1 && L <= 32, MCCNN_E_UNSUPPORTED,
+                  "mccnn_cross_arms_pair: L=%d outside [1,32] (5-bit arms, 12-bit region size)", L);
+    return launch_cross_arms(image_left, image_right, support_left, support_right, 2, H, W, tau, L, (hipStream_t)stream);
 }
 
 extern "C" int mccnn_cross_region_list(const mccnn_support_t *support, int H, int W, int L, int32_t *region,

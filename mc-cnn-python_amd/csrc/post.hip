@@ -31,28 +31,70 @@ __global__ __launch_bounds__(256) void wta_kernel(const float *__restrict__ vol,
 }
 
 // ---- a8 interpolation (pf:279-378) ------------------------------------------------------------------------------
+// One workgroup per image row.  pf:299-303 asks, for a pixel w whose own disparity failed the check, whether ANY d in
+// [0, min(w+1, D)) has |d - dr[w-d]| <= 1 - a walk over up to D right-map pixels per pixel.  Turned around: a right-map
+// pixel x with value r can satisfy that only for d within a few integers of r, i.e. for w = x + d in a handful of
+// places; every thread evaluates the reference's own float32 expression for those candidates of its x and sets the
+// bits of the w it hits in a row mask in LDS.  Same predicate, same arithmetic, O(1) per pixel.
+constexpr int LR_MAX_WORDS = 512;   // rows up to 16384 pixels; wider rows take lr_status_walk_kernel
+
 __global__ __launch_bounds__(256) void lr_status_kernel(const float *__restrict__ dl, const float *__restrict__ dr,
                                                         int H, int W, int D, int32_t *__restrict__ status)
+{
+    __shared__ uint32_t hit[LR_MAX_WORDS];
+    const int h = blockIdx.x, tid = threadIdx.x;
+    const float *drow = dr + (size_t)h * W;
+    const int nwords = (W + 31) >> 5;
+    for (int i = tid; i < nwords; i += 256) hit[i] = 0u;
+    __syncthreads();
+    for (int x = tid; x < W; x += 256) {
+        const float r = drow[x];
+        if (!(fabsf(r) < 1.0e6f)) continue;          // NaN / inf / absurd values match no d < D
+        const int f = (int)floorf(r);
+#pragma unroll
+        for (int k = -2; k <= 3; ++k) {              // |d - r| <= 1 in float32 implies d within [floor(r) - 2, floor(r) + 3]
+            const int d = f + k, w = x + d;
+            if (d >= 0 && d < D && w < W && fabsf((float)d - r) <= 1.f) atomicOr(&hit[w >> 5], 1u << (w & 31));
+        }
+    }
+    __syncthreads();
+    for (int w = tid; w < W; w += 256) {
+        const float lf = dl[(size_t)h * W + w];
+        const int ld = (int)lf;  // pf:287 int() truncation
+        int st;
+        if (!(lf >= 0.f) || w < ld) {
+            // pf:289-291.  A negative or NaN disparity cannot come out of the reference (its WTA asserts a finite
+            // minimum, pf:253); mccnn_wta writes -1 for a pixel whose costs are all NaN/+inf, and such a pixel is treated
+            // as occluded here instead of indexing the right map out of bounds.
+            st = 2;
+        } else if (fabsf((float)ld - drow[w - ld]) <= 1.f) {
+            st = 0;  // pf:294
+        } else {
+            st = (hit[w >> 5] >> (w & 31)) & 1u ? 1 : 2;   // pf:299-303
+        }
+        status[(size_t)h * W + w] = st;
+    }
+}
+
+__global__ __launch_bounds__(256) void lr_status_walk_kernel(const float *__restrict__ dl, const float *__restrict__ dr,
+                                                             int H, int W, int D, int32_t *__restrict__ status)
 {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     const int h = blockIdx.y;
     if (w >= W) return;
     const float *drow = dr + (size_t)h * W;
     const float lf = dl[(size_t)h * W + w];
-    const int ld = (int)lf;  // pf:287 int() truncation
+    const int ld = (int)lf;
     int st;
     if (!(lf >= 0.f) || w < ld) {
-        // pf:289-291.  A negative or NaN disparity cannot come out of the reference (its WTA asserts a finite minimum,
-        // pf:253); mccnn_wta writes -1 for a pixel whose costs are all NaN/+inf, and such a pixel is treated as occluded
-        // here instead of indexing the right map out of bounds.
         st = 2;
     } else if (fabsf((float)ld - drow[w - ld]) <= 1.f) {
-        st = 0;  // pf:294
+        st = 0;
     } else {
         st = 2;
         const int lim = min(w + 1, D);
         for (int d = 0; d < lim; ++d)
-            if (fabsf((float)d - drow[w - d]) <= 1.f) { st = 1; break; }  // pf:299-303
+            if (fabsf((float)d - drow[w - d]) <= 1.f) { st = 1; break; }
     }
     status[(size_t)h * W + w] = st;
 }
@@ -490,8 +532,12 @@ extern "C" int mccnn_lr_status(const float *disp_left, const float *disp_right, 
     using namespace mccnn;
     MCCNN_REQUIRE(disp_left && disp_right && status, MCCNN_E_INVALID, "mccnn_lr_status: null pointer");
     MCCNN_REQUIRE(D > 0 && H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_lr_status: non-positive size");
-    hipLaunchKernelGGL(lr_status_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, (hipStream_t)stream, disp_left,
-                       disp_right, H, W, D, status);
+    if (W <= 32 * LR_MAX_WORDS)
+        hipLaunchKernelGGL(lr_status_kernel, dim3(H), dim3(256), 0, (hipStream_t)stream, disp_left, disp_right, H, W, D,
+                           status);
+    else
+        hipLaunchKernelGGL(lr_status_walk_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, (hipStream_t)stream, disp_left,
+                           disp_right, H, W, D, status);
     return check_launch("mccnn_lr_status");
 }
 

@@ -30,12 +30,16 @@ constexpr int kNT = 2;
 
 
 // ---- flag planes ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sgm_flags_kernel(const float *__restrict__ img, int H, int W, int rh, int rw,
-                                                        float thr, int pitch, int pad, uint8_t *__restrict__ plane)
+// blockIdx.z selects the image (0: left, 1: right): both flag planes of a pass in one launch
+__global__ __launch_bounds__(256) void sgm_flags_kernel(const float *__restrict__ img_l, const float *__restrict__ img_r,
+                                                        int H, int W, int rh, int rw, float thr, int pitch, int pad,
+                                                        uint8_t *__restrict__ plane_l, uint8_t *__restrict__ plane_r)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;  // padded column
     const int h = blockIdx.y;
     if (i >= pitch) return;
+    const float *__restrict__ img = blockIdx.z ? img_r : img_l;
+    uint8_t *__restrict__ plane = blockIdx.z ? plane_r : plane_l;
     const int x = i - pad;
     float diff = 0.f;  // D2 stays 0 where the reference `continue`s (pf:507)
     const int xp = x - rw, hp = h - rh;
@@ -576,9 +580,9 @@ extern "C" int mccnn_sgm_pass(const float *image_left, const float *image_right,
     const int pitch = W + 2 * pad;
     uint8_t *plane_l = reinterpret_cast<uint8_t *>(scratch);
     uint8_t *plane_r = plane_l + (((size_t)H * pitch + 127) & ~(size_t)127);
-    const dim3 fgrid(cdiv(pitch, 256), H), fblock(256);
-    hipLaunchKernelGGL(sgm_flags_kernel, fgrid, fblock, 0, s, image_left, H, W, rh, rw, thr, pitch, pad, plane_l);
-    hipLaunchKernelGGL(sgm_flags_kernel, fgrid, fblock, 0, s, image_right, H, W, rh, rw, thr, pitch, pad, plane_r);
+    const dim3 fgrid(cdiv(pitch, 256), H, 2), fblock(256);
+    hipLaunchKernelGGL(sgm_flags_kernel, fgrid, fblock, 0, s, image_left, image_right, H, W, rh, rw, thr, pitch, pad,
+                       plane_l, plane_r);
     int rc = check_launch("mccnn_sgm_pass(flags)");
     if (rc) return rc;
 
@@ -635,9 +639,9 @@ extern "C" int mccnn_sgm_first_pass(const float *image_left, const float *image_
     const int pitch = W + 2 * pad;
     uint8_t *plane_l = reinterpret_cast<uint8_t *>(scratch);
     uint8_t *plane_r = plane_l + (((size_t)H * pitch + 127) & ~(size_t)127);
-    const dim3 fgrid(cdiv(pitch, 256), H), fblock(256);
-    hipLaunchKernelGGL(sgm_flags_kernel, fgrid, fblock, 0, s, image_left, H, W, 0, 1, thr, pitch, pad, plane_l);
-    hipLaunchKernelGGL(sgm_flags_kernel, fgrid, fblock, 0, s, image_right, H, W, 0, 1, thr, pitch, pad, plane_r);
+    const dim3 fgrid(cdiv(pitch, 256), H, 2), fblock(256);
+    hipLaunchKernelGGL(sgm_flags_kernel, fgrid, fblock, 0, s, image_left, image_right, H, W, 0, 1, thr, pitch, pad,
+                       plane_l, plane_r);
     int rc = check_launch("mccnn_sgm_first_pass(flags)");
     if (rc) return rc;
     SgmFirstParams P;

@@ -34,6 +34,7 @@ SIGNATURES = {
     "mccnn_cost_volume": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "mccnn_support_bytes": (_sz, [_i, _i]),
     "mccnn_cross_arms": (_i, [_vp, _i, _i, _f, _i, _vp, _vp]),
+    "mccnn_cross_arms_pair": (_i, [_vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp]),
     "mccnn_cross_region_list": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mccnn_cbca_iter": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mccnn_cbca_iter_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

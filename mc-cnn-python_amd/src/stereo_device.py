@@ -160,6 +160,19 @@ def cross_arms(image, intensity_threshold, distance_threshold, out=None):
     return support
 
 
+def cross_arms_pair(image_l, image_r, intensity_threshold, distance_threshold, out_l=None, out_r=None):
+    """cross_arms() on both views in one call (half the launches); returns (support_l, support_r)."""
+    H, W = image_l.shape
+    if tuple(image_r.shape) != (H, W):
+        raise ValueError("cross_arms_pair: the two images must have the same shape")
+    sl = out_l if out_l is not None else support_buffer(H, W, image_l.device)
+    sr = out_r if out_r is not None else support_buffer(H, W, image_l.device)
+    hip.check(hip.load().mccnn_cross_arms_pair(hip.ptr(image_l), hip.ptr(image_r), H, W, _f32(intensity_threshold),
+                                               int(distance_threshold), hip.ptr(sl), hip.ptr(sr), hip.stream()),
+              "mccnn_cross_arms_pair")
+    return sl, sr
+
+
 def support_arms(support):
     """uint8 [H,W,4]: up, down, left, right."""
     s = support.to(torch.int64) & 0xFFFFFFFF
@@ -511,8 +524,7 @@ class StereoMatcher(object):
             keep["cv"] = (lcv.clone(), rcv.clone())
 
         timer.start("cross_arms")
-        sup_l = cross_arms(L, hp["cbca_intensity"], hp["cbca_distance"], out=ws["sup_l"])
-        sup_r = cross_arms(R, hp["cbca_intensity"], hp["cbca_distance"], out=ws["sup_r"])
+        sup_l, sup_r = cross_arms_pair(L, R, hp["cbca_intensity"], hp["cbca_distance"], ws["sup_l"], ws["sup_r"])
         timer.stop()
 
         ex = self.extras

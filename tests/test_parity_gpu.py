@@ -359,6 +359,23 @@ def test_oracle_interpolation_mask_kernels(pf, H, W):
         assert_bits(pf.interpolation(dl, dr, D), o.interpolation(dl, dr, D), "interpolation %dx%d %g" % (W, H, dens))
 
 
+def test_cross_arms_pair_equals_two_calls(sd):
+    """mccnn_cross_arms_pair (both views, one launch per kernel) writes the same three support planes as two
+    mccnn_cross_arms calls."""
+    g = torch.Generator(device="cuda").manual_seed(21)
+    for H, W in ((37, 300), (64, 64), (5, 1)):
+        a = torch.nn.functional.avg_pool2d(torch.rand((1, 1, H, W), device="cuda", generator=g), 3, 1, 1)[0, 0].contiguous()
+        b = torch.nn.functional.avg_pool2d(torch.rand((1, 1, H, W), device="cuda", generator=g), 3, 1, 1)[0, 0].contiguous()
+        sa, sb = sd.cross_arms(a, 0.02, 14), sd.cross_arms(b, 0.02, 14)
+        pa, pb = sd.cross_arms_pair(a, b, 0.02, 14)
+        v = -torch.rand((3, H, W), device="cuda", generator=g)
+        for x, y in ((sa, pa), (sb, pb)):
+            assert torch.equal(x, y)                       # arms + region sizes
+            rx, _ = sd.cbca(v.clone(), torch.empty_like(v), x, 2, 14)   # the derived planes, through their consumer
+            ry, _ = sd.cbca(v.clone(), torch.empty_like(v), y, 2, 14)
+            assert torch.equal(rx, ry)
+
+
 def test_layout_round_trip(sd):
     rng = np.random.default_rng(0)
     for (D, H, W) in [(5, 7, 9), (64, 33, 65), (130, 20, 70)]:
