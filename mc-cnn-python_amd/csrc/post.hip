@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64) void interpolate_vertical_kernel(const int32_t 
     if (w >= W) return;
     uint32_t last = 0xffffu;
     if (blockIdx.y == 0) {   // half-word 0: nearest match above
-#pragma unroll 8
+#pragma unroll 32
         for (int y = 0; y < H; ++y) {
             const size_t p = (size_t)y * W + w;
             const int s = st[p];
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64) void interpolate_vertical_kernel(const int32_t 
             if (s == 0) last = (uint32_t)y;
         }
     } else {                 // half-word 1: nearest match below
-#pragma unroll 8
+#pragma unroll 32
         for (int y = H - 1; y >= 0; --y) {
             const size_t p = (size_t)y * W + w;
             const int s = st[p];
@@ -429,6 +429,70 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const float *__restrict_
     out[(size_t)h * W + w] = vsum / wsum;
 }
 
+// The reference's 5x5 window (match.py:170): interior pixels have all 25 taps, so the window walk and NumPy's summation
+// order (8 running sums over taps 0..23, the fixed combine tree, then tap 24, then + identity) unroll completely and
+// everything stays in registers; the general kernel keeps its taps in indexed arrays, i.e. in scratch memory.  Border
+// pixels (clipped windows, other tap counts and orders) take the general code.
+__global__ __launch_bounds__(256) void bilateral5x5_kernel(const float *__restrict__ img, const float *__restrict__ dl,
+                                                           int H, int W, const float *__restrict__ table, float thr,
+                                                           float *__restrict__ out)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    const int h = blockIdx.y;
+    if (w >= W) return;
+    const float cur = img[(size_t)h * W + w];
+    if (h >= 2 && h + 2 < H && w >= 2 && w + 2 < W) {
+        float wgt[25], val[25];
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 5; ++dx) {
+                const size_t q = (size_t)(h + dy - 2) * W + (w + dx - 2);
+                const float t = img[q] - cur;
+                const float sq = t * t;
+                const float diff = sqrtf(sq);                                   // pf:458-459
+                const float gate = diff < thr ? 1.f : 0.f;                      // pf:460
+                const float f = gate * table[dy * 5 + dx];                      // pf:462
+                wgt[dy * 5 + dx] = f;
+                val[dy * 5 + dx] = f * dl[q];                                   // pf:465
+            }
+        float sums[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float *a = k ? val : wgt;
+            float r[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = a[j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] += a[8 + j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] += a[16 + j];
+            float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+            res += a[24];
+            sums[k] = 0.f + res;
+        }
+        out[(size_t)h * W + w] = sums[1] / sums[0];
+        return;
+    }
+    const int hs = max(0, h - 2), he = min(H, h + 3), ws = max(0, w - 2), we = min(W, w + 3);
+    float wgt[25], val[25];
+    int n = 0;
+    for (int y = hs; y < he; ++y)
+        for (int x = ws; x < we; ++x) {
+            const float t = img[(size_t)y * W + x] - cur;
+            const float sq = t * t;
+            const float diff = sqrtf(sq);
+            const float gate = diff < thr ? 1.f : 0.f;
+            const float f = gate * table[(2 + (y - h)) * 5 + (2 + (x - w))];
+            wgt[n] = f;
+            val[n] = f * dl[(size_t)y * W + x];
+            ++n;
+        }
+    const float wsum = np_sum_small(wgt, n);
+    const float vsum = np_sum_small(val, n);
+    out[(size_t)h * W + w] = vsum / wsum;
+}
+
 // ---- a1 epilogues -------------------------------------------------------------------------------------------------
 // bias (+ ReLU) in place over an NCHW tensor: blockIdx.y = n*C + c, 4 consecutive elements per thread (planes start at
 // arbitrary 4-byte offsets, so the 16-byte accesses are declared 4-byte aligned)
@@ -637,8 +701,12 @@ extern "C" int mccnn_bilateral(const float *image, const float *disp, int H, int
     MCCNN_REQUIRE(disp != out, MCCNN_E_INVALID, "mccnn_bilateral: out must not alias the input map");
     MCCNN_REQUIRE(fh >= 1 && fw >= 1 && (fh & 1) && (fw & 1) && fh * fw <= MAXWIN, MCCNN_E_UNSUPPORTED,
                   "mccnn_bilateral: window %dx%d must be odd x odd with at most %d taps", fh, fw, MAXWIN);
-    hipLaunchKernelGGL(bilateral_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, (hipStream_t)stream, image, disp, H, W,
-                       fh, fw, table, thr, out);
+    if (fh == 5 && fw == 5)
+        hipLaunchKernelGGL(bilateral5x5_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, (hipStream_t)stream, image, disp, H,
+                           W, table, thr, out);
+    else
+        hipLaunchKernelGGL(bilateral_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, (hipStream_t)stream, image, disp, H, W,
+                           fh, fw, table, thr, out);
     return check_launch("mccnn_bilateral");
 }
 
