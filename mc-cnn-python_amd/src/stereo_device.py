@@ -473,6 +473,7 @@ class StereoMatcher(object):
             self.extras.update(extras)
         self._ws = {}
         self._graphs = {}
+        self._side = None
 
     def workspace(self, H, W, D):
         key = (H, W, D)
@@ -509,6 +510,17 @@ class StereoMatcher(object):
         hwd = (H, W, hwd_pitch(D))
         nd, nh = D * H * W, H * W * hwd[2]
 
+        # The support arms depend on the images only: without per-stage timing they run on a side stream under the
+        # conv stack (a latency-bound pair of small launches beside matrix-core work) and join before the first CBCA
+        overlap = timer is _NO_TIMER
+        if overlap:
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            main = torch.cuda.current_stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                sup_l, sup_r = cross_arms_pair(L, R, hp["cbca_intensity"], hp["cbca_distance"], ws["sup_l"], ws["sup_r"])
+
         timer.start("features")
         if self.features == "split_f16":
             fl, fr = self.net.features_pair_hwc_split(L, R)
@@ -523,9 +535,12 @@ class StereoMatcher(object):
         if keep is not None:
             keep["cv"] = (lcv.clone(), rcv.clone())
 
-        timer.start("cross_arms")
-        sup_l, sup_r = cross_arms_pair(L, R, hp["cbca_intensity"], hp["cbca_distance"], ws["sup_l"], ws["sup_r"])
-        timer.stop()
+        if overlap:
+            torch.cuda.current_stream().wait_stream(self._side)
+        else:
+            timer.start("cross_arms")
+            sup_l, sup_r = cross_arms_pair(L, R, hp["cbca_intensity"], hp["cbca_distance"], ws["sup_l"], ws["sup_r"])
+            timer.stop()
 
         ex = self.extras
 
