@@ -427,7 +427,10 @@ __global__ __launch_bounds__(64 * PPW * (NSCAN + NHS + NEMIT)) void cbca_stream_
     const StreamJobs jobs, int D, int H, int W, int rows, int nstrips, int nchunks, int total, int nfull)
 {
     using namespace s4;
-    constexpr int NPF = 4;                      // batches of loads every wave keeps in flight
+#ifndef CBCA_NPF
+#define CBCA_NPF 4
+#endif
+    constexpr int NPF = CBCA_NPF;               // batches of loads every wave keeps in flight
     constexpr int SR = B / NSCAN, ER = B / NEMIT;
     constexpr int PROW_BYTES = 2 * B * PROWB;   // double-buffered by batch parity
     constexpr int NW = NSCAN + NHS + NEMIT;     // waves of one pipeline

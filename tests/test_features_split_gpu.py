@@ -67,7 +67,7 @@ def nets(net_layers):
     return {"converted reference checkpoint": trained, "random init": random_init}
 
 
-@pytest.mark.parametrize("H,W", [(16, 32), (37, 61), (120, 200), (75, 333)])
+@pytest.mark.parametrize("H,W", [(2, 3), (3, 200), (16, 32), (37, 61), (120, 200), (75, 333)])
 def test_split_features_as_close_to_float64_as_the_library_path(nets, H, W):
     record = {}
     for name, net in nets.items():
