@@ -333,11 +333,107 @@ __global__ __launch_bounds__(256) void cbca_both_views_kernel(const float *__res
     }
 }
 
+// The reference's flat running sum (pf:157-161) for FOUR planes at once.  The walk over a pixel's region is one
+// dependent float32 chain per output by definition, and the kernel above spends its time on what surrounds each
+// link of it (an LDS read, the wait, the loop bookkeeping of a divergent walk: ~8 instructions per element, with the
+// wave waiting for its longest walk - on the synthetic pair the mean region has 30 pixels, the mean over waves of the
+// largest region 127): 3.5 of its 4.1 ms per iteration at 750x500x256.  The support region does not
+// depend on the disparity, so a lane can walk once for its pixel in four neighbouring planes: the tile is staged as
+// float4 per pixel, one ds_read_b128 fetches the four values and two v_pk_add_f32 advance the four chains - the
+// same additions in the same order per plane (packed float32 adds are IEEE adds), a quarter of the instructions:
+// 3.3 ms.  Measured and dropped: the arms in LDS instead of a global load per row (3.5 ms: the lower occupancy costs
+// more), chunked walks with the reads of a chunk issued together and lanes past their arm adding -0.0f, the exact
+// identity (3.6 ms: more work for the typical short arm).  What is left is divergence - lanes waiting for the longest
+// walk in their wave.
+typedef float cb_f2 __attribute__((ext_vector_type(2)));
+
+template <int R, int TH>
+__global__ __launch_bounds__(256) void cbca_ref4_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                        const Support *__restrict__ sup, int D, int H, int W)
+{
+    constexpr int IW = CB_TW + 2 * R, IH = TH + 2 * R;
+    __shared__ float4 tin[IH * IW];
+    const int tid = threadIdx.x;
+    const int w0 = blockIdx.x * CB_TW, h0 = blockIdx.y * TH, d0 = blockIdx.z * 4;
+    const size_t plane = (size_t)H * W;
+    auto aL = [](uint32_t a) { return min(arm_left(a), R); };
+    auto aR = [](uint32_t a) { return min(arm_right(a), R); };
+    auto aU = [](uint32_t a) { return min(arm_up(a), R); };
+    auto aD = [](uint32_t a) { return min(arm_down(a), R); };
+    const float *src[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) src[p] = in + (size_t)min(d0 + p, D - 1) * plane;   // a short last group repeats a plane
+    for (int i = tid; i < IH * IW; i += 256) {
+        const int r = i / IW, c = i - r * IW;
+        const int hh = h0 - R + r, ww = w0 - R + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
+            const size_t q = (size_t)hh * W + ww;
+            v = make_float4(src[0][q], src[1][q], src[2][q], src[3][q]);
+        }
+        tin[i] = v;
+    }
+    __syncthreads();
+    const int c = tid & 63;
+    const int ww = w0 + c;
+    for (int k = 0; k < TH / 4; ++k) {
+        const int r = (tid >> 6) + 4 * k;
+        const int hh = h0 + r;
+        if (hh < H && ww < W) {
+            const Support sp = sup[(size_t)hh * W + ww];
+            cb_f2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
+            const int nu = aU(sp), nv = 1 + nu + aD(sp);
+            auto add = [&](const float4 x) {
+                const cb_f2 a = {x.x, x.y}, b = {x.z, x.w};
+                s01 += a;
+                s23 += b;
+            };
+            // the arms of the next row are fetched while this row is summed, and the first PRE entries of both arms
+            // are read together with the anchor (unconditionally: the staged halo is R >= PRE columns wide)
+            constexpr int PRE = R < 2 ? R : 2;
+            auto offset = [&](int v) { return v == 0 ? 0 : (v <= nu ? -v : v - nu); };
+            uint32_t aq_next = sp;
+            for (int v = 0; v < nv; ++v) {
+                const int dq = offset(v);
+                const uint32_t aq = aq_next;
+                if (v + 1 < nv) aq_next = sup[(size_t)(hh + offset(v + 1)) * W + ww];
+                const float4 *row = &tin[(r + R + dq) * IW + c + R];
+                const int nl = aL(aq), nr = aR(aq);
+                const float4 x0 = row[0];
+                float4 xl[PRE], xr[PRE];
+#pragma unroll
+                for (int z = 0; z < PRE; ++z) {
+                    xl[z] = row[-1 - z];
+                    xr[z] = row[1 + z];
+                }
+                add(x0);
+#pragma unroll
+                for (int z = 0; z < PRE; ++z)
+                    if (z < nl) add(xl[z]);
+                for (int z = PRE + 1; z <= nl; ++z) add(row[-z]);
+#pragma unroll
+                for (int z = 0; z < PRE; ++z)
+                    if (z < nr) add(xr[z]);
+                for (int z = PRE + 1; z <= nr; ++z) add(row[z]);
+            }
+            const float n = (float)sup_count(sp);
+            const float res[4] = {s01.x / n, s01.y / n, s23.x / n, s23.y / n};   // pf:161
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (d0 + p < D) out[(size_t)(d0 + p) * plane + (size_t)hh * W + ww] = res[p];
+        }
+    }
+}
+
 template <int R, int CB_TH>
 static int launch_cbca(const float *in, float *out, const Support *sup, int D, int H, int W, int order, hipStream_t s)
 {
     const dim3 grid(cdiv(W, CB_TW), cdiv(H, CB_TH), D), block(256);
-    if (order == MCCNN_CBCA_REFERENCE_ORDER)
+    if (order == MCCNN_CBCA_REFERENCE_ORDER && R <= 13) {
+        constexpr int TH4 = 16;   // 42 x 90 float4 = 59 KiB of LDS: two workgroups per CU
+        hipLaunchKernelGGL((cbca_ref4_kernel<(R <= 13 ? R : 13), TH4>), dim3(cdiv(W, CB_TW), cdiv(H, TH4), cdiv(D, 4)),
+                           block, 0, s, in, out, sup, D, H, W);
+    } else if (order == MCCNN_CBCA_REFERENCE_ORDER)
         hipLaunchKernelGGL((cbca_iter_kernel<R, CB_TH, true>), grid, block, 0, s, in, out, sup, H, W);
     else
         hipLaunchKernelGGL((cbca_iter_kernel<R, CB_TH, false>), grid, block, 0, s, in, out, sup, H, W);
