@@ -67,11 +67,14 @@ int mccnn_cost_volume(const float *fl, const float *fr, int H, int W, int C, int
  *     bits 0-4 up | 5-9 down | 10-14 left | 15-19 right | 20-31 count        (arms <= 31, count <= 63*63)
  * hence L <= 32.  The reference's explicit coordinate list [H][W][(2L)^2][2] (padded with -1) is produced by
  * mccnn_cross_region_list for API compatibility only.
- * The support buffer holds two derived planes behind the first (each 16-byte aligned), private to the streaming kernel
- * of mccnn_cbca_iter and written for its LDS layout: [H][W] uint32 "hsum words" (LDS byte addresses of the two row-prefix
+ * The support buffer holds three derived planes behind the first (each 16-byte aligned), private to the kernels
+ * of mccnn_cbca_iter.  Two are written for the streaming kernel's LDS layout: [H][W] uint32 "hsum words" (LDS byte addresses of the two row-prefix
  * entries whose difference is the pixel's horizontal-arm sum) and [H][W] uint64 "emit words" (the float64 reciprocal
  * 1/count with the vertical arms in its 12 low mantissa bits; the 40 upper mantissa bits are chosen so that the word as
- * stored is the float64 nearest to 1/count).  Allocate mccnn_support_bytes(H, W) bytes (16 per pixel + alignment);
+ * stored is the float64 nearest to 1/count).  The third lists, for every 16 x 64 pixel tile, its pixels in order of
+ * falling region size (uint16 tile-local indices): the order in which the reference-order kernel deals pixels to lanes,
+ * so that a wave's lanes walk regions of similar size.  Allocate mccnn_support_bytes(H, W) bytes (18 per pixel +
+ * alignment);
  * mccnn_cross_arms fills all planes, and consumers that only want the arms / counts read the first H*W words. */
 typedef uint32_t mccnn_support_t; /* plane 0 layout [H][W] */
 size_t mccnn_support_bytes(int H, int W); /* whole buffer: all planes (0 for non-positive sizes) */

@@ -120,6 +120,17 @@ __host__ __device__ constexpr uint32_t elem(int i) { return (uint32_t)((i % CPS)
 //                          word AS IT IS (fields included) is the float64 nearest to 1/n among the words with those low
 //                          bits - the kernel multiplies by it without masking (|rel. error| <= 2^-41).
 __host__ __device__ __forceinline__ size_t hsum_plane_offset(int H, int W) { return ((size_t)H * W * 4 + 15) & ~(size_t)15; }
+// fourth plane: for every 16 x 64 pixel tile its 1024 pixels ordered by falling region size (uint16 tile-local
+// indices row * 64 + column), which is the order cbca_ref4_kernel deals them to lanes in
+constexpr int PERM_TH = 16, CB_TW_C = 64;
+__host__ __device__ __forceinline__ size_t perm_plane_offset(int H, int W)
+{
+    return (hsum_plane_offset(H, W) + (size_t)H * W * 4 + (size_t)H * W * 8 + 31) & ~(size_t)15;
+}
+__host__ __device__ __forceinline__ size_t perm_plane_bytes(int H, int W)
+{
+    return (size_t)((W + CB_TW_C - 1) / CB_TW_C) * ((H + PERM_TH - 1) / PERM_TH) * (PERM_TH * CB_TW_C) * 2;
+}
 __host__ __device__ __forceinline__ size_t emit_plane_offset(int H, int W)
 {
     return (hsum_plane_offset(H, W) + (size_t)H * W * 4 + 15) & ~(size_t)15;
@@ -183,6 +194,52 @@ __global__ __launch_bounds__(256) void cross_region_list_kernel(const Support *_
 // ---------------------------------------------------------------------------------------------------------------
 // LDS-tiled aggregation: a workgroup stages a (TH+2R) x (TW+2R) tile of one disparity plane (R = halo = longest arm).
 constexpr int CB_TW = 64;  // output tile width  (one wave = one full output row)
+
+// Counting sort of a 16 x 64 tile's pixels by falling region size (ties in arbitrary order: the order only decides
+// which lane walks which pixel).  Pixels outside the image sort last (size 0).  blockIdx.z selects the view.
+__global__ __launch_bounds__(256) void cross_perm_kernel(const Support *__restrict__ sup0, const Support *__restrict__ sup1,
+                                                         int H, int W)
+{
+    constexpr int NB = 1024;                    // bins: region sizes are clamped to 1023 (<= 729 for distances <= 14)
+    __shared__ int bins[NB];
+    __shared__ int wsum[4];
+    const Support *sup = blockIdx.z ? sup1 : sup0;
+    uint16_t *perm = reinterpret_cast<uint16_t *>(const_cast<char *>(reinterpret_cast<const char *>(sup)) +
+                                                  perm_plane_offset(H, W)) +
+                     ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (PERM_TH * CB_TW_C);
+    const int tid = threadIdx.x, w0 = blockIdx.x * CB_TW_C, h0 = blockIdx.y * PERM_TH;
+    for (int i = tid; i < NB; i += 256) bins[i] = 0;
+    __syncthreads();
+    int key[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = tid + 256 * k, hh = h0 + (idx >> 6), ww = w0 + (idx & 63);
+        const int n = (hh < H && ww < W) ? min((int)sup_count(sup[(size_t)hh * W + ww]), NB - 1) : 0;
+        key[k] = NB - 1 - n;                    // ascending key = falling size
+        atomicAdd(&bins[key[k]], 1);
+    }
+    __syncthreads();
+    // exclusive prefix over the bins: 4 bins per thread, wave scan, wave totals through LDS
+    const int b0 = bins[4 * tid], b1 = bins[4 * tid + 1], b2 = bins[4 * tid + 2], b3 = bins[4 * tid + 3];
+    int incl = b0 + b1 + b2 + b3;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if ((tid & 63) >= off) incl += t;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    int base = incl - (b0 + b1 + b2 + b3);
+    for (int wv = 0; wv < (tid >> 6); ++wv) base += wsum[wv];
+    __syncthreads();
+    bins[4 * tid] = base;
+    bins[4 * tid + 1] = base + b0;
+    bins[4 * tid + 2] = base + b0 + b1;
+    bins[4 * tid + 3] = base + b0 + b1 + b2;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) perm[atomicAdd(&bins[key[k]], 1)] = (uint16_t)(tid + 256 * k);
+}
 
 template <int R, int CB_TH, bool REF_ORDER>
 __global__ __launch_bounds__(256) void cbca_iter_kernel(const float *__restrict__ in, float *__restrict__ out,
@@ -374,11 +431,18 @@ __global__ __launch_bounds__(256) void cbca_ref4_kernel(const float *__restrict_
         tin[i] = v;
     }
     __syncthreads();
-    const int c = tid & 63;
-    const int ww = w0 + c;
+    // Pixels are dealt to lanes in the order of the tile's permutation plane (falling region size): the 64 lanes of a
+    // wave then walk regions of nearly equal size instead of waiting for the largest of 64 neighbours.  The 16 groups
+    // of 64 go to the four waves in snake order (w, 7-w, 8+w, 15-w), so the waves finish together too.
+    static_assert(TH == PERM_TH, "the permutation plane is built for 16-row tiles");
+    const uint16_t *perm = reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(sup) + perm_plane_offset(H, W)) +
+                           ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (TH * CB_TW);
+    const int wv = tid >> 6, ln = tid & 63;
     for (int k = 0; k < TH / 4; ++k) {
-        const int r = (tid >> 6) + 4 * k;
-        const int hh = h0 + r;
+        const int grp = (k & 1) ? 4 * k + 3 - wv : 4 * k + wv;
+        const int idx = perm[grp * 64 + ln];
+        const int r = idx >> 6, c = idx & 63;
+        const int hh = h0 + r, ww = w0 + c;
         if (hh < H && ww < W) {
             const Support sp = sup[(size_t)hh * W + ww];
             cb_f2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
@@ -881,6 +945,9 @@ static int launch_cross_arms(const float *img0, const float *img1, mccnn_support
     if (rc) return rc;
     hipLaunchKernelGGL(cross_count_kernel, grid, block, 0, s, sup0, sup1, H, W);
     rc = check_launch("mccnn_cross_arms(count)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(cross_perm_kernel, dim3(cdiv(W, CB_TW_C), cdiv(H, PERM_TH), n), block, 0, s, sup0, sup1, H, W);
+    rc = check_launch("mccnn_cross_arms(order)");
     if (rc == 0) {
         std::lock_guard<std::mutex> lock(g_support_mu);
         if (g_support.size() > 4096) g_support.clear();   // bounded: stale entries only cost a missed check
@@ -893,7 +960,7 @@ static int launch_cross_arms(const float *img0, const float *img1, mccnn_support
 extern "C" size_t mccnn_support_bytes(int H, int W)
 {
     if (H <= 0 || W <= 0) return 0;
-    return mccnn::emit_plane_offset(H, W) + (size_t)H * W * 8;
+    return mccnn::perm_plane_offset(H, W) + mccnn::perm_plane_bytes(H, W);
 }
 
 extern "C" int mccnn_cross_arms(const float *image, int H, int W, float tau, int L, mccnn_support_t *support,
