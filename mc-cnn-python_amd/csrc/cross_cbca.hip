@@ -195,12 +195,12 @@ __global__ __launch_bounds__(256) void cross_region_list_kernel(const Support *_
 // LDS-tiled aggregation: a workgroup stages a (TH+2R) x (TW+2R) tile of one disparity plane (R = halo = longest arm).
 constexpr int CB_TW = 64;  // output tile width  (one wave = one full output row)
 
-// Counting sort of a 16 x 64 tile's pixels by falling region size (ties in arbitrary order: the order only decides
-// which lane walks which pixel).  Pixels outside the image sort last (size 0).  blockIdx.z selects the view.
+// Counting sort of a 16 x 64 tile's pixels by falling walk cost (ties in arbitrary order: the order only decides
+// which lane walks which pixel).  Pixels outside the image sort last.  blockIdx.z selects the view.
 __global__ __launch_bounds__(256) void cross_perm_kernel(const Support *__restrict__ sup0, const Support *__restrict__ sup1,
                                                          int H, int W)
 {
-    constexpr int NB = 1024;                    // bins: region sizes are clamped to 1023 (<= 729 for distances <= 14)
+    constexpr int NB = 1024;                    // bins: keys are below 28 * 32
     __shared__ int bins[NB];
     __shared__ int wsum[4];
     const Support *sup = blockIdx.z ? sup1 : sup0;
@@ -214,8 +214,16 @@ __global__ __launch_bounds__(256) void cross_perm_kernel(const Support *__restri
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int idx = tid + 256 * k, hh = h0 + (idx >> 6), ww = w0 + (idx & 63);
-        const int n = (hh < H && ww < W) ? min((int)sup_count(sup[(size_t)hh * W + ww]), NB - 1) : 0;
-        key[k] = NB - 1 - n;                    // ascending key = falling size
+        // key: number of rows of the region (1 + up + down) first, its mean width second - the walk costs a wave the
+        // most rows among its lanes times the widest arm on each of them, so rows matter most (keyed by region size
+        // alone: 2.10 instead of 1.87 ms per iteration)
+        int n = 0;
+        if (hh < H && ww < W) {
+            const Support a = sup[(size_t)hh * W + ww];
+            const int rows = 1 + min((int)arm_up(a), 13) + min((int)arm_down(a), 13);      // 1 .. 27
+            n = (rows << 5) | min((int)sup_count(a) / rows, 31);
+        }
+        key[k] = NB - 1 - n;                    // ascending key = falling cost
         atomicAdd(&bins[key[k]], 1);
     }
     __syncthreads();
