@@ -112,7 +112,22 @@ def test_cfg1_whole_pair_stage_by_stage(net_layers):
     RECORD["cfg1_fast_vs_exact"] = {"wta_flips": flips, "pixels": int(fast_map.size),
                                     "fraction_within_1e-3_px": close,
                                     "max_abs_px": float(np.nanmax(np.abs(fast_map - exact_map)))}
+    # the same fast variants with the conv features from the split-operand matrix-core kernels (what --fast and bench.py
+    # run): features against the float64 restatement, final map against the bit-exact run
+    sfl = net.features_pair_hwc_split(dev(L[:, :, 0]), dev(R[:, :, 0]))
+    RECORD["cfg1_split_features_max_abs_vs_float64_restatement"] = float(np.abs(sfl[0].cpu().numpy() - ofl).max())
+    m = sd.StereoMatcher(net, cv_mode=hip.MCCNN_CV_MFMA, cbca_order=hip.MCCNN_CBCA_SEPARABLE, features="split_f16")
+    keep_s = {}
+    split_map = m.match(dev(L), dev(R), D, keep=keep_s).cpu().numpy()
+    flips_s = int((keep_s["wta"][0].cpu().numpy() != exact_wta).sum())
+    close_s = float(np.isclose(split_map, exact_map, atol=1e-3, equal_nan=True).mean())
+    RECORD["cfg1_fast_with_split_features_vs_exact"] = {
+        "wta_flips": flips_s, "pixels": int(split_map.size), "fraction_within_1e-3_px": close_s,
+        "max_abs_px": float(np.nanmax(np.abs(split_map - exact_map)))}
     _dump()
+    assert RECORD["cfg1_split_features_max_abs_vs_float64_restatement"] <= 1e-5
+    assert flips_s <= split_map.size // 500, "split features: %d WTA flips of %d" % (flips_s, split_map.size)
+    assert close_s >= 0.985, "split features: only %.4f of the pixels within 1e-3 px of the bit-exact run" % close_s
     assert cv_err <= 2e-6
     assert d["cbca_x2"] <= 2 * 8 * float(np.spacing(np.float32(1.0)))          # <= 8 spacings of max|input| per iteration
     # 16 iterations on post-SGM costs (|v| up to ~200), regions up to 729 pixels: measured 60 spacings of max|input|
