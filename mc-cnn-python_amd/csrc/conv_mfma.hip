@@ -40,8 +40,12 @@ typedef float f16x __attribute__((ext_vector_type(16)));
 typedef uint32_t w4 __attribute__((ext_vector_type(4)));
 typedef uint32_t w2 __attribute__((ext_vector_type(2)));
 
+#ifndef CONV_NBW
+#define CONV_NBW 4                           // rows of 32 pixels per wave (4: one workgroup per CU; 2: two)
+#endif
 namespace cs {
-constexpr int TH = 16, TW = 32;              // output tile
+constexpr int NBW = CONV_NBW;
+constexpr int TH = 4 * NBW, TW = 32;         // output tile
 constexpr int IH = TH + 2, IW = TW + 2;      // input pixels of a tile
 constexpr int NPIX = IH * IW;                // 612
 constexpr int SLOT = 80;                     // LDS bytes per staged pixel (one channel group): hi 32, lo 32, pad 16
@@ -49,7 +53,8 @@ constexpr int QBUF = NPIX * SLOT;            // 48 960
 constexpr int NITEM = NPIX * 4;              // 16-byte pieces per staged group
 constexpr int NST = (NITEM + 255) / 256;     // 10 per thread
 constexpr int EPITCH = 272;                  // epilogue scratch: 256-byte record + 16 (keeps b128 alignment)
-constexpr int EPI = 32 * EPITCH;             // per wave: one row of 32 pixels
+constexpr int EPX = NBW >= 4 ? 32 : 16;       // pixels of a row that pass through the epilogue scratch at a time
+constexpr int EPI = EPX * EPITCH;            // per wave
 constexpr int LDS_BYTES = 2 * QBUF + 4 * EPI;   // 132 736
 constexpr int REC = 256;                     // bytes per pixel record
 constexpr int WFRAG = 1024;                  // bytes per packed weight fragment
@@ -238,13 +243,13 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
 #pragma unroll
     for (int i = 0; i < NSLOT - 1; ++i) fetch_a(i, i);
 
-    const int bfrag = (wave * 4 * IW + (lane & 31)) * SLOT + 16 * (lane >> 5);
+    const int bfrag = (wave * NBW * IW + (lane & 31)) * SLOT + 16 * (lane >> 5);
     char *const epi = lds + 2 * QBUF + wave * EPI;
 
     while (true) {
-        f16x acc[4][2];
+        f16x acc[NBW][2];
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
+        for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
             // fragment read right before its MFMAs waits out the LDS latency with at most two MFMAs in the pipe
             w4 bf[2][2];
             auto read_b = [&](int slot, int step) {
-                const int tap = step >> 2, nb = step & 3;
+                const int tap = step / NBW, nb = step % NBW;
                 const int dy = tap / 3, dx = tap - dy * 3;
                 const char *pb = bq + ((nb + dy) * IW + dx) * SLOT;
                 bf[slot][0] = *reinterpret_cast<const w4 *>(pb);
@@ -291,9 +296,9 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
                 const h8 a_hi0 = __builtin_bit_cast(h8, af[slot][0]), a_hi1 = __builtin_bit_cast(h8, af[slot][1]);
                 const h8 a_lo0 = __builtin_bit_cast(h8, af[slot][2]), a_lo1 = __builtin_bit_cast(h8, af[slot][3]);
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb) {
-                    const int step = tap * 4 + nb;
-                    if (step + 1 < 36) read_b((step + 1) & 1, step + 1);
+                for (int nb = 0; nb < NBW; ++nb) {
+                    const int step = tap * NBW + nb;
+                    if (step + 1 < 9 * NBW) read_b((step + 1) & 1, step + 1);
                     __builtin_amdgcn_sched_barrier(0);   // the reads above are issued before the MFMAs below
                     const h8 b_hi = __builtin_bit_cast(h8, bf[step & 1][0]);
                     const h8 b_lo = __builtin_bit_cast(h8, bf[step & 1][1]);
@@ -307,11 +312,11 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
                 // the pieces fetched at the start of this group go to the other buffer two per tap from tap 4 on (they
                 // have landed: the A fragment waits since tap 3 are behind them in the in-order vmcnt queue), so the
                 // LDS writes run under the MFMAs instead of in front of the barrier
-                if (tap >= 9 - NST / 2) {
+                if (tap >= 9 - (NST + 1) / 2) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const int r = 2 * (tap - (9 - NST / 2)) + j;
-                        if (r < NST - 1 || last_piece) *reinterpret_cast<w4 *>(other + loff[r]) = st[r];
+                        const int r = 2 * (tap - (9 - (NST + 1) / 2)) + j;
+                        if (r < NST && (r < NST - 1 || last_piece)) *reinterpret_cast<w4 *>(other + loff[r]) = st[r];
                     }
                 }
             }
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
         {
             float t = 0.f;
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
+            for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
         }
 #else
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
+        for (int nb = 0; nb < NBW; ++nb) {
             float y[2][16];      // MODE 0: relu(x) * act_scale, clamped to the f16 range; MODE 1: x
             float ss = 0.f;
 #pragma unroll
@@ -355,36 +360,44 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
                 ss += __shfl_xor(ss, 32);
                 nrm = 1.f / sqrtf(fmaxf(ss, 1e-12f));
             }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int ch = 32 * mb + 8 * g + 4 * half;          // first of 4 consecutive maps
-                    if (MODE == 0) {
-                        w2 hi, lo;
-                        split4_scaled(&y[mb][4 * g], hi, lo);
-                        char *p = epi + px * EPITCH + (ch >> 4) * 64 + (ch & 15) * 2;
-                        *reinterpret_cast<w2 *>(p) = hi;
-                        *reinterpret_cast<w2 *>(p + 32) = lo;
-                    } else {
-                        w4 o;
-                        o.x = __float_as_uint(y[mb][4 * g + 0] * nrm);
-                        o.y = __float_as_uint(y[mb][4 * g + 1] * nrm);
-                        o.z = __float_as_uint(y[mb][4 * g + 2] * nrm);
-                        o.w = __float_as_uint(y[mb][4 * g + 3] * nrm);
-                        *reinterpret_cast<w4 *>(epi + px * EPITCH + ch * 4) = o;
-                    }
-                }
-            __builtin_amdgcn_wave_barrier();
-            const int row = ty0 + wave * 4 + nb;
+            // the row passes through the wave's scratch EPX pixels at a time (all 32, or two halves of 16 where two
+            // workgroups share a CU's LDS): the lanes owning those pixels write, the wave reads whole records back
+            const int row = ty0 + wave * NBW + nb;
             const int so = ((n * Ho + row) * Wo + tx0) * REC;            // wave-uniform
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int i = it * 64 + lane, p = i >> 4, part = i & 15;
-                const w4 o = *reinterpret_cast<const w4 *>(epi + p * EPITCH + part * 16);
-                const bool ok = row < Ho && tx0 + p < Wo;
-                __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, ok ? p * REC + part * 16 : 0x7ffffff0, so, 0);
+            for (int hf = 0; hf < 32 / EPX; ++hf) {
+                __builtin_amdgcn_wave_barrier();
+                if (EPX == 32 || (px >> 4) == hf) {
+                    const int pl = px & (EPX - 1);
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int ch = 32 * mb + 8 * g + 4 * half;          // first of 4 consecutive maps
+                            if (MODE == 0) {
+                                w2 hi, lo;
+                                split4_scaled(&y[mb][4 * g], hi, lo);
+                                char *p = epi + pl * EPITCH + (ch >> 4) * 64 + (ch & 15) * 2;
+                                *reinterpret_cast<w2 *>(p) = hi;
+                                *reinterpret_cast<w2 *>(p + 32) = lo;
+                            } else {
+                                w4 o;
+                                o.x = __float_as_uint(y[mb][4 * g + 0] * nrm);
+                                o.y = __float_as_uint(y[mb][4 * g + 1] * nrm);
+                                o.z = __float_as_uint(y[mb][4 * g + 2] * nrm);
+                                o.w = __float_as_uint(y[mb][4 * g + 3] * nrm);
+                                *reinterpret_cast<w4 *>(epi + pl * EPITCH + ch * 4) = o;
+                            }
+                        }
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < EPX / 4; ++it) {
+                    const int i = it * 64 + lane, pl = i >> 4, part = i & 15, p = hf * EPX + pl;
+                    const w4 o = *reinterpret_cast<const w4 *>(epi + pl * EPITCH + part * 16);
+                    const bool ok = row < Ho && tx0 + p < Wo;
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, ok ? p * REC + part * 16 : 0x7ffffff0, so, 0);
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -448,7 +461,8 @@ extern "C" int mccnn_conv3x3_split(const void *in, const void *packed_weights, c
             c = 256;
         return c & ~7;
     }();
-    const int grid = (int)(total < cus ? total : cus);
+    const long slots = (long)cus * (LDS_BYTES <= 80 * 1024 ? 2 : 1);     // resident workgroups
+    const int grid = (int)(total < slots ? total : slots);
     const float inv = 1.f / (weight_scale * act_scale);
     hipStream_t s = (hipStream_t)stream;
     if (last) {
