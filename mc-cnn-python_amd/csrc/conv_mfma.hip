@@ -6,10 +6,11 @@
 // as two f16 numbers, x * s = hi + lo with hi = f16(x * s), lo = f16(x * s - hi) (s a power of two chosen so that
 // both parts stay normal numbers): 22 significand bits.  A product a * b becomes three MFMA terms
 //     a_hi * b_hi + a_hi * b_lo + a_lo * b_hi          (the a_lo * b_lo term is below 2^-22 relative)
-// accumulated in float32 by the matrix core.  Measured against a float64 evaluation of the stack the result is as
-// close as the float32 library path (tests/test_features_split_gpu.py records both) - it is float32-equivalent
-// arithmetic on f16 hardware, not a reduced-precision mode, but it is NOT bit-identical to any float32 evaluation
-// order, so it is selected explicitly (StereoMatcher(features="split_f16"), match.py --fast).
+// accumulated in float32 by the matrix core.  Measured against a float64 evaluation of the stack the unit feature
+// vectors are off by 5e-7 where the float32 library path is off by 2.5e-7 (tests/test_features_split_gpu.py records
+// both; the golden feature test allows 1e-5) - float32-class arithmetic on f16 hardware, not a reduced-precision mode,
+// but NOT bit-identical to any float32 evaluation order, so it is selected explicitly
+// (StereoMatcher(features="split_f16"), match.py --fast).
 //
 // Activations live in HBM as "split records": 256 bytes per pixel, [q = channel / 16][hi 16 x f16 | lo 16 x f16],
 // pixel-major ([N][H][W][256 B]).  A record has the size of the pixel's 64 float32 values; the last layer writes those
@@ -22,9 +23,10 @@
 //   * B: the 18 x 34 input pixels of the tile, channel group q only, are staged in LDS (80-byte slots: hi 32 B, lo
 //     32 B, 16 B pad - conflict-free ds_read_b128 for 32 consecutive pixels); a tap is an immediate offset.  Two
 //     buffers: group q+1 (or the next tile's group 0) is fetched into registers while group q is multiplied, and
-//     written to the other buffer before the one barrier per group.
+//     written to the other buffer under the MFMAs of the group's last taps; one barrier per group.
 //   * A: packed on the device once per weight set (mccnn_conv3x3_split_pack) in fragment order, 1 KiB per (K step,
-//     part, map block), read from global memory (L1/L2 resident: 144 KiB per layer) two K steps ahead.
+//     part, map block), read from global memory (L1/L2 resident: 144 KiB per layer) three K steps ahead; B
+//     fragments one step of 6 MFMAs ahead.
 //   * per K step and wave: 4 A fragments, 8 B fragments, 24 MFMAs (768 cycles of the SIMD's matrix core).
 // Epilogue: x / (s_a s_w) + bias, ReLU, split again (or L2-normalise), through a per-wave LDS scratch so that the
 // stores are whole 256-byte records, 1 KiB per wave instruction.
