@@ -121,7 +121,11 @@ constexpr int CVM_TP = 68;   // LDS pitch of the folded product tile T[(w-x) & 6
 
 __device__ __forceinline__ void cv_split4(const float4 v, cv_h4 &hi, cv_h4 &lo)
 {
-    const float x[4] = {v.x * 1024.f, v.y * 1024.f, v.z * 1024.f, v.w * 1024.f};
+    // unit vectors never get near the clamp (|x| <= 1 -> 1024); it keeps features that are not normalised finite
+    const float x[4] = {__builtin_amdgcn_fmed3f(v.x * 1024.f, -65504.f, 65504.f),
+                        __builtin_amdgcn_fmed3f(v.y * 1024.f, -65504.f, 65504.f),
+                        __builtin_amdgcn_fmed3f(v.z * 1024.f, -65504.f, 65504.f),
+                        __builtin_amdgcn_fmed3f(v.w * 1024.f, -65504.f, 65504.f)};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const _Float16 h = (_Float16)x[j];
