@@ -225,8 +225,6 @@ __global__ __launch_bounds__(256, CVM_WAVES_PER_SIMD) void cost_volume_mfma_kern
     const int dbase = w0 - x0;  // d of the main diagonal
     // A lane stores 4 consecutive w of one diagonal (16 B, dword aligned) to both volumes - the vector-memory pipe
     // costs about the same per wave instruction whatever its width; one instruction covers 4 rows of T x 16 quads.
-    // The quad of a row that straddles the fold holds the last elements of one diagonal and the first of the other:
-    // element by element.
     typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
     const int q = lane & 15, sub = lane >> 4;
     for (int rgp = wave; rgp < 16; rgp += 4) {
@@ -254,15 +252,20 @@ __global__ __launch_bounds__(256, CVM_WAVES_PER_SIMD) void cost_volume_mfma_kern
                         pr[j] = v[j];
                     }
             }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int d = dbase + (wl + j >= row ? row : row - 64);
-                if (d >= 0 && d < D && w + j < W) {
-                    lcv[(size_t)d * plane + rowbase + w + j] = v[j];
-                    rcv[(size_t)d * plane + rowbase + (w + j - d)] = v[j];
-                }
-            }
+        }
+    }
+    // The quad of a row that straddles the fold (rows not divisible by 4) holds the last elements of one diagonal and
+    // the first of the other: one element per thread, all lanes busy - 2 store instructions per wave instead of 8
+    // nearly empty ones inside every iteration of the loop above.
+    {
+        const int row = tid >> 2, j = tid & 3;
+        const int c = (row & ~3) + j;                     // column of the element in its row of T
+        const int d = dbase + (c >= row ? row : row - 64);
+        const int w = w0 + c;
+        if ((row & 3) != 0 && d >= 0 && d < D && w < W) {
+            const float v = sT[row * CVM_TP + c];
+            lcv[(size_t)d * plane + rowbase + w] = v;
+            rcv[(size_t)d * plane + rowbase + (w - d)] = v;
         }
     }
 }
