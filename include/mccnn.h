@@ -124,6 +124,20 @@ int mccnn_cbca_iter_both(const float *in, float *out, const mccnn_support_t *sup
                          const mccnn_support_t *support_other, int D, int H, int W, int L, int side,
                          mccnn_stream_t stream);
 
+/* ---- a4 on the pixel-major layout: ONE iteration in the reference's summation order, bit-exact (pf:149-163) ----
+ * in_hwd / out_hwd are "HWD" volumes [H][W][Dp]; out[p,d] = the reference's flat float32 running sum over the region
+ * list of p (vertical arm self,up..,down.. x horizontal arm self,left..,right..) divided by count[p].  A wave owns a
+ * few neighbouring pixels and all their disparities (disparities on lanes), so the region walk runs on the scalar
+ * unit and every region element is one coalesced load: same bits as mccnn_cbca_iter(..., MCCNN_CBCA_REFERENCE_ORDER)
+ * on the plane-major volume, an order of magnitude faster.  Only plane 0 of the support buffer is read (up to 28
+ * bytes past its last word, inside the buffer mccnn_support_bytes sizes).  L <= 14 (arms <= 13); in != out.
+ * The _pair form takes the left and the right volume in one launch (pf:116-180 loops over the two views). */
+int mccnn_cbca_iter_hwd(const float *in_hwd, float *out_hwd, const mccnn_support_t *support, int D, int H, int W, int L,
+                        mccnn_stream_t stream);
+int mccnn_cbca_iter_hwd_pair(const float *in_left, float *out_left, const mccnn_support_t *support_left,
+                             const float *in_right, float *out_right, const mccnn_support_t *support_right, int D,
+                             int H, int W, int L, mccnn_stream_t stream);
+
 /* ---- layout changes between DHW and HWD ------------------------------------------------------------------- */
 int mccnn_hwd_pitch(int D); /* Dp: D rounded up to a multiple of 4 (16-byte rows) */
 int mccnn_dhw_to_hwd(const float *dhw, float *hwd, int D, int H, int W, mccnn_stream_t stream);
@@ -154,6 +168,9 @@ int mccnn_sgm_first_pass(const float *image_left, const float *image_right, cons
  * negative or NaN disparity as an occlusion. */
 int mccnn_wta(const float *vol_dhw, int D, int H, int W, float *disparity, mccnn_stream_t stream);
 
+/* The same on a pixel-major volume [H][W][Dp] (one 1 KiB run per pixel at D = 256): same index, same -1 rule. */
+int mccnn_wta_hwd(const float *vol_hwd, int D, int H, int W, float *disparity, mccnn_stream_t stream);
+
 /* ---- a8  interpolation (pf:279-378) -------------------------------------------------------------------------
  * mccnn_lr_status: 0 match, 1 mismatch, 2 occlusion (pf:285-307).  mccnn_interpolate: status 1 -> median of the
  * nearest status-0 pixel right/left/below/above, status 2 -> nearest status-0 pixel to the right, else raw. */
@@ -174,6 +191,10 @@ int mccnn_subpixel(const float *disp, const float *vol_dhw, int D, int H, int W,
  * differs from the default by <= 2.5e-5 px.  0 == mccnn_subpixel (what the golden vectors pin). */
 int mccnn_subpixel_ex(const float *disp, const float *vol_dhw, int D, int H, int W, int numpy1_promotion, float *out,
                       mccnn_stream_t stream);
+
+/* mccnn_subpixel_ex on a pixel-major volume [H][W][Dp]: the same arithmetic, three neighbouring floats per pixel. */
+int mccnn_subpixel_hwd(const float *disp, const float *vol_hwd, int D, int H, int W, int numpy1_promotion, float *out,
+                       mccnn_stream_t stream);
 
 /* ---- a10 median_filter (pf:403-421): clipped fh x fw window (odd sizes, fh*fw <= 49), np.median ------------- */
 int mccnn_median(const float *disp, int H, int W, int fh, int fw, float *out, mccnn_stream_t stream);

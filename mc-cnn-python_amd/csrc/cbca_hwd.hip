@@ -1,0 +1,422 @@
+// a4 cost_volume_aggregation (/root/reference/src/process_functional.py:117-183) in the reference's own summation
+// order - bit-exact - on the pixel-major "HWD" layout [H][W][Dp], plus the two volume readers that let the whole
+// bit-exact pair stay pixel-major (a7 WTA pf:239-272, a9 sub-pixel pf:381-400).
+//
+//   out[p, d] = ( sum_{q in Vert(p): self, up 1..u, down 1..dn}  sum_{r in Horiz(q): self, left 1..l, right 1..r}  in[r, d] ) / |U(p)|
+// as ONE flat float32 running sum per (p, d) starting from 0 (pf:149-163): the order of the additions is part of the
+// result, so every output is a dependent chain of |U(p)| adds (mean 30, up to 27 x 27 = 729 on the synthetic pair).
+//
+// Why disparities on lanes.  The plane-major reference-order kernel (cbca_ref4_kernel, cross_cbca.hip) gives every lane
+// its own pixel and pays for it with a divergent walk: a wave waits for its longest region, each region row starts
+// with a dependent load of that row's arms, and every element costs loop bookkeeping in vector instructions - 1.87 ms
+// per volume iteration at 750x500x256, 5 % of the HBM roofline, for ~0.04 ms worth of float32 adds.  The support
+// region does not depend on the disparity.  With the volume pixel-major, a wave takes a pixel and ALL its disparities
+// (lane l owns d = 4 l .. 4 l + 3, exactly sgm_pass_kernel's mapping): the walk is wave-uniform, i.e. it runs on the
+// scalar unit (arms by s_load, loop counters and addresses in SGPRs, s_cbranch per element), no lane ever waits for
+// another, every region element is one coalesced 1 KiB buffer_load_dwordx4 with a wave-uniform offset, and the loads
+// are independent of the add chains, so a whole region row is in flight at once.
+//
+// Why G pixels per wave.  Done pixel by pixel, every add needs its own 1 KiB operand from the vector memory pipe
+// (64 B/clk/CU): 375 K pixels x 30 elements x 1 KiB = 11.5 GB per volume iteration, 0.3 ms at the pipe's peak.  G
+// horizontally adjacent pixels share most of every region row, and they visit the rows in the same order (self, up
+// 1.., down 1..; a pixel simply sits out the rows beyond its own vertical arm).  So a wave owns G neighbours: per
+// row it loads the union of their horizontal arms ONCE into a register window (slot = column, statically indexed -
+// the chains are fully unrolled and every element is guarded by a scalar branch), then runs each pixel's chain over
+// the window in that pixel's own order.  Same additions, same order, per (pixel, d): bit-exact.  Loads per pixel and
+// row fall from ~6 to ~9/4.
+//
+// HBM sees each voxel once (8 B/voxel/iteration, like the streaming kernel): the re-reads are served by L2.  The
+// launch is XCD-aware for that: workgroup b runs on XCD b % 8, every XCD owns a band of image rows, and inside a band
+// the workgroups sweep column by column (4 rows x G columns per workgroup), so that the ~400 waves an XCD has
+// resident cover a compact window of the image whose rows stay in that XCD's 4 MiB L2 while they are being reused.
+#include "support.h"
+
+namespace mccnn {
+namespace hw {
+
+constexpr int R = 13;                 // longest arm served (distance threshold L <= 14)
+constexpr int kDrop = 0x7ffffff0;     // byte offset past every buffer: the range check drops the access
+
+#ifndef CBCA_HWD_G
+#define CBCA_HWD_G 4                  // pixels per wave
+#endif
+constexpr int G = CBCA_HWD_G;
+constexpr int NW = G + 2 * R;         // window slots: columns x0 - R .. x0 + G - 1 + R
+static_assert(NW <= 64, "window mask is 64 bits");
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int VPL> struct Vec;
+template <> struct Vec<4> {
+    typedef float T __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ T load(__amdgpu_buffer_rsrc_t rs, int voff, unsigned soff)
+    {
+        const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+        T v;
+        v.x = __uint_as_float(u.x); v.y = __uint_as_float(u.y); v.z = __uint_as_float(u.z); v.w = __uint_as_float(u.w);
+        return v;
+    }
+    static __device__ __forceinline__ void store(T v, __amdgpu_buffer_rsrc_t rs, int voff, unsigned soff)
+    {
+        u32x4 u;
+        u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+        __builtin_amdgcn_raw_buffer_store_b128(u, rs, voff, soff, 0);
+    }
+    static __device__ __forceinline__ T zero() { T v = {0.f, 0.f, 0.f, 0.f}; return v; }
+};
+template <> struct Vec<2> {
+    typedef float T __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ T load(__amdgpu_buffer_rsrc_t rs, int voff, unsigned soff)
+    {
+        const u32x2 u = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+        T v;
+        v.x = __uint_as_float(u.x); v.y = __uint_as_float(u.y);
+        return v;
+    }
+    static __device__ __forceinline__ void store(T v, __amdgpu_buffer_rsrc_t rs, int voff, unsigned soff)
+    {
+        u32x2 u;
+        u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y);
+        __builtin_amdgcn_raw_buffer_store_b64(u, rs, voff, soff, 0);
+    }
+    static __device__ __forceinline__ T zero() { T v = {0.f, 0.f}; return v; }
+};
+
+// The chains.  J (pixel of the group) and Z (distance along the arm) are template parameters, so every window access
+// has a compile-time index (the window lives in registers) and every element is one scalar compare + branch.
+template <int VPL, int J, int Z>
+__device__ __forceinline__ void walk_left(typename Vec<VPL>::T &a, const typename Vec<VPL>::T (&win)[NW], int nl)
+{
+    if constexpr (Z <= R) {
+        if (nl >= Z) {
+            a += win[J + R - Z];
+            walk_left<VPL, J, Z + 1>(a, win, nl);
+        }
+    }
+}
+template <int VPL, int J, int Z>
+__device__ __forceinline__ void walk_right(typename Vec<VPL>::T &a, const typename Vec<VPL>::T (&win)[NW], int nr)
+{
+    if constexpr (Z <= R) {
+        if (nr >= Z) {
+            a += win[J + R + Z];
+            walk_right<VPL, J, Z + 1>(a, win, nr);
+        }
+    }
+}
+// pf:157-161 for pixel J on one region row: self, left 1..nl, right 1..nr (nl < 0: the pixel sits this row out)
+template <int VPL, int J>
+__device__ __forceinline__ void walk_rows(typename Vec<VPL>::T (&acc)[G], const typename Vec<VPL>::T (&win)[NW],
+                                          const int (&nl)[G], const int (&nr)[G])
+{
+    if constexpr (J < G) {
+        if (nl[J] >= 0) {
+            acc[J] += win[J + R];
+            walk_left<VPL, J, 1>(acc[J], win, nl[J]);
+            walk_right<VPL, J, 1>(acc[J], win, nr[J]);
+        }
+        walk_rows<VPL, J + 1>(acc, win, nl, nr);
+    }
+}
+template <int VPL, int K>
+__device__ __forceinline__ void load_window(typename Vec<VPL>::T (&win)[NW], unsigned long long mask,
+                                            __amdgpu_buffer_rsrc_t rs, int voff, unsigned rowoff, unsigned pix)
+{
+    if constexpr (K < NW) {
+        if ((mask >> K) & 1ull) win[K] = Vec<VPL>::load(rs, voff, rowoff + (unsigned)K * pix);
+        load_window<VPL, K + 1>(win, mask, rs, voff, rowoff, pix);
+    }
+}
+
+// One launch aggregates up to two volumes of the same shape (left and right view, each with its own support plane).
+struct Jobs {
+    const float *in[2];
+    float *out[2];
+    const Support *sup[2];
+    int n;
+};
+
+// grid = (8 * nyb, ngroups, nchunks * jobs): blockIdx.x & 7 = XCD = band of `band_rows` image rows (a multiple of 4),
+// blockIdx.x >> 3 = group of 4 rows inside the band (one row per wave), blockIdx.y = group of G columns,
+// blockIdx.z = (job, chunk of 64 * VPL disparities).  Dispatch order is x fastest, then y: inside its band an XCD
+// sweeps column group by column group.
+template <int VPL>
+__global__ __launch_bounds__(256) void cbca_hwd_kernel(const Jobs jobs, int Dp, int H, int W, int nchunks, int band_rows)
+{
+    typedef typename Vec<VPL>::T vf;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int y = (int)(blockIdx.x & 7) * band_rows + (int)(blockIdx.x >> 3) * 4 + wv;
+    if (y >= H) return;
+    const int x0 = (int)blockIdx.y * G;
+    const int job = (int)blockIdx.z / nchunks, chunk = (int)blockIdx.z - job * nchunks;
+    const float *const in = job ? jobs.in[1] : jobs.in[0];
+    float *const out = job ? jobs.out[1] : jobs.out[0];
+    const Support *__restrict__ const sup = job ? jobs.sup[1] : jobs.sup[0];
+
+    const unsigned pix = (unsigned)Dp * 4u;                       // bytes between neighbouring pixels
+    const int row0 = max(y - R, 0), row1 = min(y + R, H - 1);      // rows any arm of this group can reach
+    const size_t rowf = (size_t)W * Dp;                            // floats per image row
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(in + (size_t)row0 * rowf), 0, (int)((size_t)(row1 - row0 + 1) * rowf * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+        out + ((size_t)y * W + x0) * Dp, 0, (int)((unsigned)min(G, W - x0) * pix), 0x00020000);
+    const int d0 = (chunk * 64 + lane) * VPL;
+    const int voff = d0 < Dp ? d0 * 4 : kDrop;                     // lanes past the disparity range: loads 0, stores dropped
+
+    // anchors: vertical arms, validity (the support words past the right edge are read - they lie inside the support
+    // buffer - but never used)
+    const Support *arow = sup + (size_t)y * W + x0;
+    uint32_t aw[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) aw[j] = arow[j];
+    bool ok[G];
+    int up[G], dn[G], umax = 0, dmax = 0;
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        ok[j] = x0 + j < W;
+        up[j] = ok[j] ? min(min(arm_up(aw[j]), R), y) : 0;         // clamps: memory safety for a foreign plane
+        dn[j] = ok[j] ? min(min(arm_down(aw[j]), R), H - 1 - y) : 0;
+        umax = max(umax, up[j]);
+        dmax = max(dmax, dn[j]);
+    }
+    const int nrows = 1 + umax + dmax;
+    auto row_of = [&](int t) { return t == 0 ? y : (t <= umax ? y - t : y + (t - umax)); };   // pf:155 list order
+
+    vf acc[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) acc[j] = Vec<VPL>::zero();         // pf:156 sum starts at 0
+
+    uint32_t nxt[G];                                               // support words of the row walked next
+#pragma unroll
+    for (int j = 0; j < G; ++j) nxt[j] = aw[j];
+    for (int t = 0; t < nrows; ++t) {
+        uint32_t cw[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) cw[j] = nxt[j];
+        const int yq = row_of(t);
+        {   // the next row's words travel while this row is loaded and summed (past the end: a harmless re-read)
+            const Support *nrow = sup + (size_t)row_of(min(t + 1, nrows - 1)) * W + x0;
+#pragma unroll
+            for (int j = 0; j < G; ++j) nxt[j] = nrow[j];
+        }
+        const bool upward = t <= umax;
+        const int v = upward ? t : t - umax;
+        int nl[G], nr[G];
+        unsigned long long mask = 0ull;
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const bool act = ok[j] && (t == 0 || (upward ? v <= up[j] : v <= dn[j]));
+            const int l = min(min(arm_left(cw[j]), R), x0 + j), r = min(min(arm_right(cw[j]), R), W - 1 - x0 - j);
+            nl[j] = act ? l : -1;
+            nr[j] = act ? r : -1;
+            if (act) mask |= ((2ull << (l + r)) - 1ull) << (j + R - l);
+        }
+        // slot k = column x0 - R + k; the offset may wrap below zero for slots left of the image, which no arm reaches
+        const unsigned rowoff = (unsigned)(((yq - row0) * W + x0 - R) * (int)pix);
+        vf win[NW];
+        load_window<VPL, 0>(win, mask, rs_in, voff, rowoff, pix);
+        walk_rows<VPL, 0>(acc, win, nl, nr);
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        if (ok[j]) {
+            const float n = (float)sup_count(aw[j]);
+            const vf res = acc[j] / n;                             // pf:161
+            Vec<VPL>::store(res, rs_out, voff, (unsigned)j * pix);
+        }
+    }
+}
+
+static int launch(const Jobs &jobs, int D, int H, int W, hipStream_t s)
+{
+    const int Dp = mccnn_hwd_pitch(D);
+    MCCNN_REQUIRE((size_t)(2 * R + 1) * W * Dp * 4 < ((size_t)1 << 31), MCCNN_E_UNSUPPORTED,
+                  "mccnn_cbca_iter_hwd: %d columns x %d disparities exceed a buffer descriptor's reach", W, D);
+    const int vpl = Dp > 128 ? 4 : 2;
+    const int nchunks = cdiv(Dp, 64 * vpl);
+    const int band_rows = cdiv(cdiv(H, 8), 4) * 4;
+    const int ngroups = cdiv(W, G);
+    MCCNN_REQUIRE(ngroups <= 65535 && nchunks * jobs.n <= 65535, MCCNN_E_UNSUPPORTED,
+                  "mccnn_cbca_iter_hwd: %dx%dx%d exceeds the grid", W, H, D);
+    const dim3 grid(8 * (band_rows / 4), ngroups, nchunks * jobs.n), block(256);
+    if (vpl == 4)
+        hipLaunchKernelGGL(cbca_hwd_kernel<4>, grid, block, 0, s, jobs, Dp, H, W, nchunks, band_rows);
+    else
+        hipLaunchKernelGGL(cbca_hwd_kernel<2>, grid, block, 0, s, jobs, Dp, H, W, nchunks, band_rows);
+    return check_launch("mccnn_cbca_iter_hwd");
+}
+
+// ---- a7 on the pixel-major volume: first strict minimum over d (pf:245-254) ----------------------------------------
+// One pixel per wave step, 4 disparities per lane and 256-disparity group; the lowest index among equal minima is
+// found by a second reduction over the candidates' indices.  8 pixels (8 KiB of loads) in flight per wave.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp_i(int old, int src)
+{
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ float wave_min_f(float x)
+{
+    // lanes without a source keep their own value (old = x)
+    auto step = [](float v, int o) { return fminf(v, __int_as_float(o)); };
+    x = step(x, dpp_i<0xB1>(__float_as_int(x), __float_as_int(x)));         // quad_perm [1,0,3,2]
+    x = step(x, dpp_i<0x4E>(__float_as_int(x), __float_as_int(x)));         // quad_perm [2,3,0,1]
+    x = step(x, dpp_i<0x141>(__float_as_int(x), __float_as_int(x)));        // row_half_mirror
+    x = step(x, dpp_i<0x140>(__float_as_int(x), __float_as_int(x)));        // row_mirror
+    x = step(x, dpp_i<0x142, 0xA>(__float_as_int(x), __float_as_int(x)));   // row_bcast:15
+    x = step(x, dpp_i<0x143, 0xC>(__float_as_int(x), __float_as_int(x)));   // row_bcast:31
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+__device__ __forceinline__ int wave_min_i(int x)
+{
+    x = min(x, dpp_i<0xB1>(x, x));
+    x = min(x, dpp_i<0x4E>(x, x));
+    x = min(x, dpp_i<0x141>(x, x));
+    x = min(x, dpp_i<0x140>(x, x));
+    x = min(x, dpp_i<0x142, 0xA>(x, x));
+    x = min(x, dpp_i<0x143, 0xC>(x, x));
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
+__global__ __launch_bounds__(256) void wta_hwd_kernel(const float *__restrict__ vol, int D, int Dp, long N,
+                                                      float *__restrict__ disp, int per_wave)
+{
+    constexpr int PF = 8;
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long n0 = wave * per_wave, n1 = min(n0 + per_wave, N);
+    if (n0 >= N) return;
+    const int ng = (Dp + 255) / 256;
+    for (long nb = n0; nb < n1; nb += PF) {
+        float best[PF];
+        int bd[PF];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            best[k] = __builtin_huge_valf();
+            bd[k] = -1;
+        }
+        for (int g = 0; g < ng; ++g) {
+            const int d = g * 256 + lane * 4;
+            float4 v[PF];
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const long n = min(nb + k, n1 - 1);
+                v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (d < Dp) v[k] = *reinterpret_cast<const float4 *>(vol + (size_t)n * Dp + d);
+            }
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                if (d + 0 < D && v[k].x < best[k]) { best[k] = v[k].x; bd[k] = d; }
+                if (d + 1 < D && v[k].y < best[k]) { best[k] = v[k].y; bd[k] = d + 1; }
+                if (d + 2 < D && v[k].z < best[k]) { best[k] = v[k].z; bd[k] = d + 2; }
+                if (d + 3 < D && v[k].w < best[k]) { best[k] = v[k].w; bd[k] = d + 3; }
+            }
+        }
+        float res = 0.f;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const float m = wave_min_f(best[k]);
+            const int cand = (best[k] == m && bd[k] >= 0) ? bd[k] : 0x7fffffff;
+            const int idx = wave_min_i(cand);
+            if (lane == k) res = idx == 0x7fffffff ? -1.f : (float)idx;   // pf:254: the index as float32
+        }
+        if (lane < PF && nb + lane < n1) disp[nb + lane] = res;
+    }
+}
+
+// ---- a9 on the pixel-major volume (pf:387-396): the same arithmetic as subpixel_kernel (post.hip) -------------------
+template <bool NUMPY1>
+__global__ __launch_bounds__(256) void subpixel_hwd_kernel(const float *__restrict__ dl, const float *__restrict__ vol,
+                                                           int D, int Dp, long N, float *__restrict__ out)
+{
+    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float d = dl[n];
+    const int im = (int)(d - 1.f), ip = (int)(d + 1.f), ic = (int)d;
+    float res = d;
+    if (!(im < 0 || ip >= D)) {
+        const float *p = vol + (size_t)n * Dp;
+        const float cm = p[im], cp = p[ip], c = p[ic];
+        const float num = cp - cm;
+        if (NUMPY1) {
+            double den = (double)cp - 2.0 * (double)c;
+            den = den + (double)cm;
+            den = 2.0 * den;
+            res = (float)((double)d - (double)num / den);
+        } else {
+            float den = cp - 2.f * c;
+            den = den + cm;
+            den = 2.f * den;
+            res = d - num / den;
+        }
+    }
+    out[n] = res;
+}
+
+}  // namespace hw
+}  // namespace mccnn
+
+extern "C" int mccnn_cbca_iter_hwd(const float *in_hwd, float *out_hwd, const mccnn_support_t *support, int D, int H,
+                                   int W, int L, mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(in_hwd && out_hwd && support, MCCNN_E_INVALID, "mccnn_cbca_iter_hwd: null pointer");
+    MCCNN_REQUIRE(in_hwd != out_hwd, MCCNN_E_INVALID, "mccnn_cbca_iter_hwd: in-place aggregation is not defined (ping-pong)");
+    MCCNN_REQUIRE(D > 0 && H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_cbca_iter_hwd: non-positive size");
+    MCCNN_REQUIRE(L >= 1 && L <= 14, MCCNN_E_UNSUPPORTED,
+                  "mccnn_cbca_iter_hwd: L=%d outside [1,14] (use mccnn_cbca_iter on the plane-major volume)", L);
+    if (const int rc = check_support_record(support, H, W, L, "mccnn_cbca_iter_hwd")) return rc;
+    const hw::Jobs jobs = {{in_hwd, nullptr}, {out_hwd, nullptr}, {support, nullptr}, 1};
+    return hw::launch(jobs, D, H, W, (hipStream_t)stream);
+}
+
+extern "C" int mccnn_cbca_iter_hwd_pair(const float *in_left, float *out_left, const mccnn_support_t *support_left,
+                                        const float *in_right, float *out_right, const mccnn_support_t *support_right,
+                                        int D, int H, int W, int L, mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(in_left && out_left && support_left && in_right && out_right && support_right, MCCNN_E_INVALID,
+                  "mccnn_cbca_iter_hwd_pair: null pointer");
+    MCCNN_REQUIRE(in_left != out_left && in_right != out_right && out_left != out_right && in_left != out_right &&
+                      in_right != out_left,
+                  MCCNN_E_INVALID, "mccnn_cbca_iter_hwd_pair: outputs must not alias an input or each other");
+    MCCNN_REQUIRE(D > 0 && H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_cbca_iter_hwd_pair: non-positive size");
+    MCCNN_REQUIRE(L >= 1 && L <= 14, MCCNN_E_UNSUPPORTED, "mccnn_cbca_iter_hwd_pair: L=%d outside [1,14]", L);
+    int rc = check_support_record(support_left, H, W, L, "mccnn_cbca_iter_hwd_pair");
+    if (rc) return rc;
+    rc = check_support_record(support_right, H, W, L, "mccnn_cbca_iter_hwd_pair");
+    if (rc) return rc;
+    const hw::Jobs jobs = {{in_left, in_right}, {out_left, out_right}, {support_left, support_right}, 2};
+    return hw::launch(jobs, D, H, W, (hipStream_t)stream);
+}
+
+extern "C" int mccnn_wta_hwd(const float *vol_hwd, int D, int H, int W, float *disparity, mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(vol_hwd && disparity, MCCNN_E_INVALID, "mccnn_wta_hwd: null pointer");
+    MCCNN_REQUIRE(D > 0 && H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_wta_hwd: non-positive size");
+    const long N = (long)H * W;
+    const int per_wave = 64;   // pixels per wave: 8 rounds of 8
+    const long waves = (N + per_wave - 1) / per_wave;
+    hipLaunchKernelGGL(hw::wta_hwd_kernel, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, (hipStream_t)stream, vol_hwd, D,
+                       mccnn_hwd_pitch(D), N, disparity, per_wave);
+    return check_launch("mccnn_wta_hwd");
+}
+
+extern "C" int mccnn_subpixel_hwd(const float *disp, const float *vol_hwd, int D, int H, int W, int numpy1_promotion,
+                                  float *out, mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(disp && vol_hwd && out, MCCNN_E_INVALID, "mccnn_subpixel_hwd: null pointer");
+    MCCNN_REQUIRE(D > 0 && H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_subpixel_hwd: non-positive size");
+    const long N = (long)H * W;
+    const dim3 grid(cdiv(N, 256)), block(256);
+    if (numpy1_promotion)
+        hipLaunchKernelGGL(hw::subpixel_hwd_kernel<true>, grid, block, 0, (hipStream_t)stream, disp, vol_hwd, D,
+                           mccnn_hwd_pitch(D), N, out);
+    else
+        hipLaunchKernelGGL(hw::subpixel_hwd_kernel<false>, grid, block, 0, (hipStream_t)stream, disp, vol_hwd, D,
+                           mccnn_hwd_pitch(D), N, out);
+    return check_launch("mccnn_subpixel_hwd");
+}

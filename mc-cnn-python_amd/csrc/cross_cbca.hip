@@ -18,18 +18,9 @@
 #include <mutex>
 #include <unordered_map>
 
-#include "common.h"
+#include "support.h"
 
 namespace mccnn {
-
-typedef uint32_t Support;  // == mccnn_support_t: bits 0-4 up, 5-9 down, 10-14 left, 15-19 right, 20-31 region size
-static_assert(sizeof(mccnn_support_t) == 4, "support record must be 4 bytes");
-
-__device__ __forceinline__ int arm_up(uint32_t a) { return (int)(a & 31u); }
-__device__ __forceinline__ int arm_down(uint32_t a) { return (int)((a >> 5) & 31u); }
-__device__ __forceinline__ int arm_left(uint32_t a) { return (int)((a >> 10) & 31u); }
-__device__ __forceinline__ int arm_right(uint32_t a) { return (int)((a >> 15) & 31u); }
-__device__ __forceinline__ int sup_count(uint32_t a) { return (int)(a >> 20); }
 
 // np.linalg.norm of the 1-vector (cur - other): sqrt(x*x), float32 (pf:588,596,615,623)
 __device__ __forceinline__ float norm1(float x)
@@ -929,7 +920,7 @@ std::mutex g_support_mu;
 std::unordered_map<const void *, SupportInfo> g_support;
 }  // namespace
 
-static int check_support_record(const mccnn_support_t *support, int H, int W, int L, const char *who)
+int mccnn::check_support_record(const mccnn_support_t *support, int H, int W, int L, const char *who)
 {
     std::lock_guard<std::mutex> lock(g_support_mu);
     const auto it = g_support.find(support);

@@ -39,6 +39,10 @@ SIGNATURES = {
     "mccnn_cbca_iter": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mccnn_cbca_iter_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mccnn_cbca_iter_both": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mccnn_cbca_iter_hwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mccnn_cbca_iter_hwd_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mccnn_wta_hwd": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "mccnn_subpixel_hwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "mccnn_hwd_pitch": (_i, [_i]),
     "mccnn_dhw_to_hwd": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "mccnn_hwd_to_dhw": (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -239,6 +239,53 @@ def cbca_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, iterations, dist
     return (sl, dl), (sr, dr)
 
 
+def _check_support(support, H, W, who):
+    have = support.untyped_storage().nbytes() - support.storage_offset() * support.element_size()
+    if tuple(support.shape) != (H, W) or not support.is_contiguous() or have < hip.load().mccnn_support_bytes(H, W):
+        raise ValueError("%s: `support` must be the tensor cross_arms() returned (a copy drops its derived planes)" % who)
+
+
+def cbca_hwd(vol, tmp, support, D, iterations, distance_threshold, timer=None):
+    """`iterations` rounds of cross-based averaging in the reference's summation order (bit-exact) on a pixel-major
+    volume [H,W,Dp] (mccnn_cbca_iter_hwd).  Same ping-pong contract as cbca(): returns (result, spare)."""
+    H, W, Dp = vol.shape
+    assert Dp == hwd_pitch(D) and tuple(tmp.shape) == (H, W, Dp)
+    _check_support(support, H, W, "cbca_hwd")
+    lib = hip.load()
+    src, dst = vol, tmp
+    timer = timer or _NO_TIMER
+    for _ in range(int(iterations)):
+        timer.start("cbca_iter_hwd")
+        hip.check(lib.mccnn_cbca_iter_hwd(hip.ptr(src), hip.ptr(dst), hip.ptr(support), int(D), H, W,
+                                          int(distance_threshold), hip.stream()), "mccnn_cbca_iter_hwd")
+        timer.stop()
+        src, dst = dst, src
+    return src, dst
+
+
+def cbca_hwd_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, D, iterations, distance_threshold, timer=None):
+    """cbca_hwd() on the left and the right volume, one launch per iteration (mccnn_cbca_iter_hwd_pair).
+    Returns ((result_l, spare_l), (result_r, spare_r))."""
+    H, W, Dp = vol_l.shape
+    assert Dp == hwd_pitch(D)
+    for t in (tmp_l, vol_r, tmp_r):
+        if tuple(t.shape) != (H, W, Dp):
+            raise ValueError("cbca_hwd_pair: the volumes must have the same shape")
+    _check_support(support_l, H, W, "cbca_hwd_pair")
+    _check_support(support_r, H, W, "cbca_hwd_pair")
+    lib = hip.load()
+    (sl, dl), (sr, dr) = (vol_l, tmp_l), (vol_r, tmp_r)
+    timer = timer or _NO_TIMER
+    for _ in range(int(iterations)):
+        timer.start("cbca_iter_hwd_pair")
+        hip.check(lib.mccnn_cbca_iter_hwd_pair(hip.ptr(sl), hip.ptr(dl), hip.ptr(support_l), hip.ptr(sr), hip.ptr(dr),
+                                               hip.ptr(support_r), int(D), H, W, int(distance_threshold),
+                                               hip.stream()), "mccnn_cbca_iter_hwd_pair")
+        timer.stop()
+        sl, dl, sr, dr = dl, sl, dr, sr
+    return (sl, dl), (sr, dr)
+
+
 def cbca_both_views(vol, tmp, support_self, support_other, iterations, distance_threshold, side, timer=None):
     """`iterations` rounds of cross-based averaging with the paper's two-view support regions (opt-in extra, see
     mccnn_cbca_iter_both): arms intersected with the other view's at the partner pixel x -/+ d.  Same ping-pong
@@ -353,6 +400,25 @@ def wta(vol, out=None):
     disp = out if out is not None else torch.empty((H, W), dtype=torch.float32, device=vol.device)
     hip.check(hip.load().mccnn_wta(hip.ptr(vol), D, H, W, hip.ptr(disp), hip.stream()), "mccnn_wta")
     return disp
+
+
+def wta_hwd(vol_hwd, D, out=None):
+    """wta() on a pixel-major volume [H,W,Dp]."""
+    H, W, Dp = vol_hwd.shape
+    assert Dp == hwd_pitch(D)
+    disp = out if out is not None else torch.empty((H, W), dtype=torch.float32, device=vol_hwd.device)
+    hip.check(hip.load().mccnn_wta_hwd(hip.ptr(vol_hwd), int(D), H, W, hip.ptr(disp), hip.stream()), "mccnn_wta_hwd")
+    return disp
+
+
+def subpixel_hwd(dl, vol_hwd, D, out=None, numpy1_promotion=False):
+    """subpixel() on a pixel-major volume [H,W,Dp]."""
+    H, W, Dp = vol_hwd.shape
+    assert Dp == hwd_pitch(D)
+    out = out if out is not None else torch.empty_like(dl)
+    hip.check(hip.load().mccnn_subpixel_hwd(hip.ptr(dl), hip.ptr(vol_hwd), int(D), H, W, 1 if numpy1_promotion else 0,
+                                            hip.ptr(out), hip.stream()), "mccnn_subpixel_hwd")
+    return out
 
 
 def lr_status(dl, dr, ndisp, out=None):
