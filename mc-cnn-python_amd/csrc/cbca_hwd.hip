@@ -34,15 +34,10 @@
 namespace mccnn {
 namespace hw {
 
-constexpr int R = 13;                 // longest arm served (distance threshold L <= 14)
-constexpr int kDrop = 0x7ffffff0;     // byte offset past every buffer: the range check drops the access
-
-#ifndef CBCA_HWD_G
-#define CBCA_HWD_G 4                  // pixels per wave
-#endif
-constexpr int G = CBCA_HWD_G;
-constexpr int NW = G + 2 * R;         // window slots: columns x0 - R .. x0 + G - 1 + R
-static_assert(NW <= 64, "window mask is 64 bits");
+constexpr int R = HWD_R;               // longest arm served (distance threshold L <= 14)
+constexpr int G = HWD_G;               // pixels per wave (support.h: the window masks are built for it)
+constexpr int NW = HWD_NW;             // window slots: columns x0 - R .. x0 + G - 1 + R
+constexpr int kDrop = 0x7ffffff0;      // byte offset past every buffer: the range check drops the access
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -84,48 +79,63 @@ template <> struct Vec<2> {
 };
 
 // The chains.  J (pixel of the group) and Z (distance along the arm) are template parameters, so every window access
-// has a compile-time index (the window lives in registers) and every element is one scalar compare + branch.
+// has a compile-time index (the window lives in registers) and every element is one scalar bit test + branch on the
+// pixel's window mask m (zero when the pixel sits the row out).
 template <int VPL, int J, int Z>
-__device__ __forceinline__ void walk_left(typename Vec<VPL>::T &a, const typename Vec<VPL>::T (&win)[NW], int nl)
+__device__ __forceinline__ void walk_left(typename Vec<VPL>::T &a, const typename Vec<VPL>::T (&win)[NW], uint32_t m)
 {
     if constexpr (Z <= R) {
-        if (nl >= Z) {
+        if (m & (1u << (J + R - Z))) {
             a += win[J + R - Z];
-            walk_left<VPL, J, Z + 1>(a, win, nl);
+            walk_left<VPL, J, Z + 1>(a, win, m);
         }
     }
 }
 template <int VPL, int J, int Z>
-__device__ __forceinline__ void walk_right(typename Vec<VPL>::T &a, const typename Vec<VPL>::T (&win)[NW], int nr)
+__device__ __forceinline__ void walk_right(typename Vec<VPL>::T &a, const typename Vec<VPL>::T (&win)[NW], uint32_t m)
 {
     if constexpr (Z <= R) {
-        if (nr >= Z) {
+        if (m & (1u << (J + R + Z))) {
             a += win[J + R + Z];
-            walk_right<VPL, J, Z + 1>(a, win, nr);
+            walk_right<VPL, J, Z + 1>(a, win, m);
         }
     }
 }
-// pf:157-161 for pixel J on one region row: self, left 1..nl, right 1..nr (nl < 0: the pixel sits this row out)
+// pf:157-161 for pixel J on one region row: self, left 1.., right 1..
 template <int VPL, int J>
 __device__ __forceinline__ void walk_rows(typename Vec<VPL>::T (&acc)[G], const typename Vec<VPL>::T (&win)[NW],
-                                          const int (&nl)[G], const int (&nr)[G])
+                                          const uint32_t (&m)[G])
 {
     if constexpr (J < G) {
-        if (nl[J] >= 0) {
+        if (m[J] & (1u << (J + R))) {
             acc[J] += win[J + R];
-            walk_left<VPL, J, 1>(acc[J], win, nl[J]);
-            walk_right<VPL, J, 1>(acc[J], win, nr[J]);
+            walk_left<VPL, J, 1>(acc[J], win, m[J]);
+            walk_right<VPL, J, 1>(acc[J], win, m[J]);
         }
-        walk_rows<VPL, J + 1>(acc, win, nl, nr);
+        walk_rows<VPL, J + 1>(acc, win, m);
     }
 }
-template <int VPL, int K>
-__device__ __forceinline__ void load_window(typename Vec<VPL>::T (&win)[NW], unsigned long long mask,
-                                            __amdgpu_buffer_rsrc_t rs, int voff, unsigned rowoff, unsigned pix)
+
+// Loads the window slots whose bits are set in `u` (the OR of the row's masks).  Two levels of scalar tests - a
+// nibble of four slots, then its slots - because a typical row touches 8-10 of the 30 slots: ~20 scalar instructions
+// instead of 3 per slot.  (A jump to the first slot of the run with fall-through from slot to slot would be cheaper
+// still, but the compiler structurises that switch into a state machine of 64-bit flags.)
+template <int VPL, int N>
+__device__ __forceinline__ void load_window(typename Vec<VPL>::T (&win)[NW], uint32_t u, __amdgpu_buffer_rsrc_t rs,
+                                            int voff, unsigned rowoff, unsigned pix)
 {
-    if constexpr (K < NW) {
-        if ((mask >> K) & 1ull) win[K] = Vec<VPL>::load(rs, voff, rowoff + (unsigned)K * pix);
-        load_window<VPL, K + 1>(win, mask, rs, voff, rowoff, pix);
+    if constexpr (4 * N < NW) {
+        if (u & (0xFu << (4 * N))) {
+            unsigned off = rowoff + (unsigned)(4 * N) * pix;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (4 * N + i < NW) {
+                    if (u & (1u << (4 * N + i))) win[4 * N + i] = Vec<VPL>::load(rs, voff, off);
+                    off += pix;
+                }
+            }
+        }
+        load_window<VPL, N + 1>(win, u, rs, voff, rowoff, pix);
     }
 }
 
@@ -154,6 +164,8 @@ __global__ __launch_bounds__(256) void cbca_hwd_kernel(const Jobs jobs, int Dp, 
     const float *const in = job ? jobs.in[1] : jobs.in[0];
     float *const out = job ? jobs.out[1] : jobs.out[0];
     const Support *__restrict__ const sup = job ? jobs.sup[1] : jobs.sup[0];
+    const uint32_t *__restrict__ const wmask =
+        reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(sup) + wmask_plane_offset(H, W));
 
     const unsigned pix = (unsigned)Dp * 4u;                       // bytes between neighbouring pixels
     const int row0 = max(y - R, 0), row1 = min(y + R, H - 1);      // rows any arm of this group can reach
@@ -165,63 +177,61 @@ __global__ __launch_bounds__(256) void cbca_hwd_kernel(const Jobs jobs, int Dp, 
     const int d0 = (chunk * 64 + lane) * VPL;
     const int voff = d0 < Dp ? d0 * 4 : kDrop;                     // lanes past the disparity range: loads 0, stores dropped
 
-    // anchors: vertical arms, validity (the support words past the right edge are read - they lie inside the support
-    // buffer - but never used)
-    const Support *arow = sup + (size_t)y * W + x0;
-    uint32_t aw[G];
+    // anchors: vertical arms and region sizes (plane 0), window masks of the anchor row.  The words of a group that
+    // straddles the right edge are read (they lie inside the support buffer) but never used: their schedule is empty.
+    const size_t p0 = (size_t)y * W + x0;
+    uint32_t aw[G], nxt[G];
 #pragma unroll
-    for (int j = 0; j < G; ++j) aw[j] = arow[j];
-    bool ok[G];
+    for (int j = 0; j < G; ++j) {
+        aw[j] = sup[p0 + j];
+        nxt[j] = wmask[p0 + j];
+    }
     int up[G], dn[G], umax = 0, dmax = 0;
 #pragma unroll
     for (int j = 0; j < G; ++j) {
-        ok[j] = x0 + j < W;
-        up[j] = ok[j] ? min(min(arm_up(aw[j]), R), y) : 0;         // clamps: memory safety for a foreign plane
-        dn[j] = ok[j] ? min(min(arm_down(aw[j]), R), H - 1 - y) : 0;
+        const bool ok = x0 + j < W;
+        up[j] = ok ? min(arm_up(aw[j]), y) : -1;                  // clamped to the image: the scalar loads below stay
+        dn[j] = ok ? min(arm_down(aw[j]), H - 1 - y) : 0;         // inside the plane whatever the words say
         umax = max(umax, up[j]);
         dmax = max(dmax, dn[j]);
     }
+    // step t of the walk visits row y (t = 0), y - t (t <= umax), y + (t - umax) (pf:155 list order: self, up, down);
+    // bit t of sched[j] says whether pixel j's vertical arm includes that row
+    uint32_t sched[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j)
+        sched[j] = up[j] < 0 ? 0u : (((2u << up[j]) - 1u) | (((1u << dn[j]) - 1u) << (umax + 1)));
     const int nrows = 1 + umax + dmax;
-    auto row_of = [&](int t) { return t == 0 ? y : (t <= umax ? y - t : y + (t - umax)); };   // pf:155 list order
 
     vf acc[G];
 #pragma unroll
     for (int j = 0; j < G; ++j) acc[j] = Vec<VPL>::zero();         // pf:156 sum starts at 0
 
-    uint32_t nxt[G];                                               // support words of the row walked next
-#pragma unroll
-    for (int j = 0; j < G; ++j) nxt[j] = aw[j];
+    int yq = y;
     for (int t = 0; t < nrows; ++t) {
-        uint32_t cw[G];
-#pragma unroll
-        for (int j = 0; j < G; ++j) cw[j] = nxt[j];
-        const int yq = row_of(t);
-        {   // the next row's words travel while this row is loaded and summed (past the end: a harmless re-read)
-            const Support *nrow = sup + (size_t)row_of(min(t + 1, nrows - 1)) * W + x0;
-#pragma unroll
-            for (int j = 0; j < G; ++j) nxt[j] = nrow[j];
-        }
-        const bool upward = t <= umax;
-        const int v = upward ? t : t - umax;
-        int nl[G], nr[G];
-        unsigned long long mask = 0ull;
+        uint32_t m[G], u = 0u;
 #pragma unroll
         for (int j = 0; j < G; ++j) {
-            const bool act = ok[j] && (t == 0 || (upward ? v <= up[j] : v <= dn[j]));
-            const int l = min(min(arm_left(cw[j]), R), x0 + j), r = min(min(arm_right(cw[j]), R), W - 1 - x0 - j);
-            nl[j] = act ? l : -1;
-            nr[j] = act ? r : -1;
-            if (act) mask |= ((2ull << (l + r)) - 1ull) << (j + R - l);
+            m[j] = (sched[j] >> t) & 1u ? nxt[j] : 0u;
+            u |= m[j];
         }
         // slot k = column x0 - R + k; the offset may wrap below zero for slots left of the image, which no arm reaches
         const unsigned rowoff = (unsigned)(((yq - row0) * W + x0 - R) * (int)pix);
+        // the next row's masks travel while this row is loaded and summed (past the end: a harmless re-read)
+        const int tn = min(t + 1, nrows - 1);
+        yq = tn == 0 ? y : (tn <= umax ? y - tn : y + (tn - umax));
+        {
+            const size_t pn = (size_t)yq * W + x0;
+#pragma unroll
+            for (int j = 0; j < G; ++j) nxt[j] = wmask[pn + j];
+        }
         vf win[NW];
-        load_window<VPL, 0>(win, mask, rs_in, voff, rowoff, pix);
-        walk_rows<VPL, 0>(acc, win, nl, nr);
+        load_window<VPL, 0>(win, u, rs_in, voff, rowoff, pix);
+        walk_rows<VPL, 0>(acc, win, m);
     }
 #pragma unroll
     for (int j = 0; j < G; ++j) {
-        if (ok[j]) {
+        if (up[j] >= 0) {
             const float n = (float)sup_count(aw[j]);
             const vf res = acc[j] / n;                             // pf:161
             Vec<VPL>::store(res, rs_out, voff, (unsigned)j * pix);
@@ -234,7 +244,11 @@ static int launch(const Jobs &jobs, int D, int H, int W, hipStream_t s)
     const int Dp = mccnn_hwd_pitch(D);
     MCCNN_REQUIRE((size_t)(2 * R + 1) * W * Dp * 4 < ((size_t)1 << 31), MCCNN_E_UNSUPPORTED,
                   "mccnn_cbca_iter_hwd: %d columns x %d disparities exceed a buffer descriptor's reach", W, D);
+#ifdef CBCA_HWD_VPL
+    const int vpl = CBCA_HWD_VPL;
+#else
     const int vpl = Dp > 128 ? 4 : 2;
+#endif
     const int nchunks = cdiv(Dp, 64 * vpl);
     const int band_rows = cdiv(cdiv(H, 8), 4) * 4;
     const int ngroups = cdiv(W, G);

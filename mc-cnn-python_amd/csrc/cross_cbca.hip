@@ -110,22 +110,6 @@ __host__ __device__ constexpr uint32_t elem(int i) { return (uint32_t)((i % CPS)
 //                          down (bits 7-11) and 31 - up (bits 2-6); the upper 40 mantissa bits are chosen so that the
 //                          word AS IT IS (fields included) is the float64 nearest to 1/n among the words with those low
 //                          bits - the kernel multiplies by it without masking (|rel. error| <= 2^-41).
-__host__ __device__ __forceinline__ size_t hsum_plane_offset(int H, int W) { return ((size_t)H * W * 4 + 15) & ~(size_t)15; }
-// fourth plane: for every 16 x 64 pixel tile its 1024 pixels ordered by falling region size (uint16 tile-local
-// indices row * 64 + column), which is the order cbca_ref4_kernel deals them to lanes in
-constexpr int PERM_TH = 16, CB_TW_C = 64;
-__host__ __device__ __forceinline__ size_t perm_plane_offset(int H, int W)
-{
-    return (hsum_plane_offset(H, W) + (size_t)H * W * 4 + (size_t)H * W * 8 + 31) & ~(size_t)15;
-}
-__host__ __device__ __forceinline__ size_t perm_plane_bytes(int H, int W)
-{
-    return (size_t)((W + CB_TW_C - 1) / CB_TW_C) * ((H + PERM_TH - 1) / PERM_TH) * (PERM_TH * CB_TW_C) * 2;
-}
-__host__ __device__ __forceinline__ size_t emit_plane_offset(int H, int W)
-{
-    return (hsum_plane_offset(H, W) + (size_t)H * W * 4 + 15) & ~(size_t)15;
-}
 
 // pf:640-653: region size = sum over the vertical arm of the horizontal arm sizes.  The size goes into the upper 12
 // bits of the same word whose lower 20 bits (the arms, written by the previous kernel and never changed here) the
@@ -157,6 +141,9 @@ __global__ __launch_bounds__(256) void cross_count_kernel(Support *__restrict__ 
     const unsigned long long field = ((unsigned long long)down << 7) | ((unsigned long long)(31 - up) << 2);
     reinterpret_cast<unsigned long long *>(base + emit_plane_offset(H, W))[p] =
         (((rbits - field + 0x800ull) >> 12) << 12) | field;
+    // window mask of the pixel-major reference-order kernel (support.h)
+    reinterpret_cast<uint32_t *>(base + wmask_plane_offset(H, W))[p] =
+        (uint32_t)(((2ull << (left + right)) - 1ull) << (w % HWD_G + HWD_R - left));
 }
 
 // pf:637-655: explicit list, order (self, up.., down..) x (self, left.., right..), padded with (-1,-1)
@@ -959,7 +946,7 @@ static int launch_cross_arms(const float *img0, const float *img1, mccnn_support
 extern "C" size_t mccnn_support_bytes(int H, int W)
 {
     if (H <= 0 || W <= 0) return 0;
-    return mccnn::perm_plane_offset(H, W) + mccnn::perm_plane_bytes(H, W);
+    return mccnn::wmask_plane_offset(H, W) + mccnn::wmask_plane_bytes(H, W);
 }
 
 extern "C" int mccnn_cross_arms(const float *image, int H, int W, float tau, int L, mccnn_support_t *support,
