@@ -38,13 +38,24 @@ constexpr int R = HWD_R;               // longest arm served (distance threshold
 constexpr int G = HWD_G;               // pixels per wave (support.h: the window masks are built for it)
 constexpr int NW = HWD_NW;             // window slots: columns x0 - R .. x0 + G - 1 + R
 constexpr int kDrop = 0x7ffffff0;      // byte offset past every buffer: the range check drops the access
+typedef hwd_mask_t wm_t;               // window mask: one bit per slot
+constexpr wm_t kOne = 1;
 
+#ifndef CBCA_HWD_WPB
+#define CBCA_HWD_WPB 1                 // waves (image rows) per workgroup
+#endif
+#ifndef CBCA_HWD_NTS
+#define CBCA_HWD_NTS 2                 // aux bits of the result stores (2 = non-temporal)
+#endif
+#ifndef CBCA_HWD_BLOCK4
+#define CBCA_HWD_BLOCK4 0
+#endif
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <int VPL> struct Vec;
 template <> struct Vec<4> {
-    typedef float T __attribute__((ext_vector_type(4)));
+    struct T { float x, y, z, w; };     // four scalars, not a vector type: see add()
     static __device__ __forceinline__ T load(__amdgpu_buffer_rsrc_t rs, int voff, unsigned soff)
     {
         const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
@@ -56,12 +67,16 @@ template <> struct Vec<4> {
     {
         u32x4 u;
         u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
-        __builtin_amdgcn_raw_buffer_store_b128(u, rs, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u, rs, voff, soff, CBCA_HWD_NTS);
     }
     static __device__ __forceinline__ T zero() { T v = {0.f, 0.f, 0.f, 0.f}; return v; }
+    // a += w as four v_add_f32: this file is built with -fno-slp-vectorize (Makefile), because clang otherwise packs the
+    // four adds into two v_pk_add_f32, which gfx950 issues at a fraction of the plain rate - same IEEE sums either way.
+    static __device__ __forceinline__ void add(T &a, const T &w) { a.x += w.x; a.y += w.y; a.z += w.z; a.w += w.w; }
+    static __device__ __forceinline__ T div(const T &a, float n) { T v = {a.x / n, a.y / n, a.z / n, a.w / n}; return v; }
 };
 template <> struct Vec<2> {
-    typedef float T __attribute__((ext_vector_type(2)));
+    struct T { float x, y; };
     static __device__ __forceinline__ T load(__amdgpu_buffer_rsrc_t rs, int voff, unsigned soff)
     {
         const u32x2 u = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
@@ -73,44 +88,59 @@ template <> struct Vec<2> {
     {
         u32x2 u;
         u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y);
-        __builtin_amdgcn_raw_buffer_store_b64(u, rs, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u, rs, voff, soff, CBCA_HWD_NTS);
     }
     static __device__ __forceinline__ T zero() { T v = {0.f, 0.f}; return v; }
+    static __device__ __forceinline__ void add(T &a, const T &w) { a.x += w.x; a.y += w.y; }
+    static __device__ __forceinline__ T div(const T &a, float n) { T v = {a.x / n, a.y / n}; return v; }
 };
 
 // The chains.  J (pixel of the group) and Z (distance along the arm) are template parameters, so every window access
-// has a compile-time index (the window lives in registers) and every element is one scalar bit test + branch on the
-// pixel's window mask m (zero when the pixel sits the row out).
-template <int VPL, int J, int Z>
-__device__ __forceinline__ void walk_left(typename Vec<VPL>::T &a, const typename Vec<VPL>::T (&win)[NW], uint32_t m)
+// has a compile-time index (the window lives in registers) and the control is scalar bit tests on the pixel's window
+// mask m (zero when the pixel sits the row out).  A wave runs this branchy serial code at one instruction per ~13
+// cycles, and the scalar test + branch of an element cost as much as its two packed adds, so long arms are taken four
+// elements per test (one s_andn2 against a 4-bit pattern) and a pixel whose region row is the pixel itself - the most
+// common case - leaves after one compare.
+template <int VPL, int J, int Z, int DIR>   // DIR = -1: left arm (slots below J + R), +1: right arm
+__device__ __forceinline__ void walk_arm(typename Vec<VPL>::T &a, const typename Vec<VPL>::T (&win)[NW], wm_t m)
 {
     if constexpr (Z <= R) {
-        if (m & (1u << (J + R - Z))) {
-            a += win[J + R - Z];
-            walk_left<VPL, J, Z + 1>(a, win, m);
-        }
-    }
-}
-template <int VPL, int J, int Z>
-__device__ __forceinline__ void walk_right(typename Vec<VPL>::T &a, const typename Vec<VPL>::T (&win)[NW], uint32_t m)
-{
-    if constexpr (Z <= R) {
-        if (m & (1u << (J + R + Z))) {
-            a += win[J + R + Z];
-            walk_right<VPL, J, Z + 1>(a, win, m);
+        if (m & (kOne << (J + R + DIR * Z))) {
+            if constexpr (CBCA_HWD_BLOCK4 && Z + 3 <= R) {
+                // bits of elements Z .. Z+3
+                constexpr wm_t four = DIR > 0 ? ((wm_t)0xF << (J + R + Z)) : ((wm_t)0xF << (J + R - Z - 3));
+                if ((~m & four) == 0) {
+                    Vec<VPL>::add(a, win[J + R + DIR * Z]);
+                    Vec<VPL>::add(a, win[J + R + DIR * (Z + 1)]);
+                    Vec<VPL>::add(a, win[J + R + DIR * (Z + 2)]);
+                    Vec<VPL>::add(a, win[J + R + DIR * (Z + 3)]);
+                    walk_arm<VPL, J, Z + 4, DIR>(a, win, m);
+                } else {                                   // the arm ends within the next three elements
+                    Vec<VPL>::add(a, win[J + R + DIR * Z]);
+                    if (m & (kOne << (J + R + DIR * (Z + 1)))) {
+                        Vec<VPL>::add(a, win[J + R + DIR * (Z + 1)]);
+                        if (m & (kOne << (J + R + DIR * (Z + 2)))) Vec<VPL>::add(a, win[J + R + DIR * (Z + 2)]);
+                    }
+                }
+            } else {
+                Vec<VPL>::add(a, win[J + R + DIR * Z]);
+                walk_arm<VPL, J, Z + 1, DIR>(a, win, m);
+            }
         }
     }
 }
 // pf:157-161 for pixel J on one region row: self, left 1.., right 1..
 template <int VPL, int J>
 __device__ __forceinline__ void walk_rows(typename Vec<VPL>::T (&acc)[G], const typename Vec<VPL>::T (&win)[NW],
-                                          const uint32_t (&m)[G])
+                                          const wm_t (&m)[G])
 {
     if constexpr (J < G) {
-        if (m[J] & (1u << (J + R))) {
-            acc[J] += win[J + R];
-            walk_left<VPL, J, 1>(acc[J], win, m[J]);
-            walk_right<VPL, J, 1>(acc[J], win, m[J]);
+        if (m[J] != 0) {
+            Vec<VPL>::add(acc[J], win[J + R]);
+            if (m[J] != (kOne << (J + R))) {
+                walk_arm<VPL, J, 1, -1>(acc[J], win, m[J]);
+                walk_arm<VPL, J, 1, +1>(acc[J], win, m[J]);
+            }
         }
         walk_rows<VPL, J + 1>(acc, win, m);
     }
@@ -121,16 +151,16 @@ __device__ __forceinline__ void walk_rows(typename Vec<VPL>::T (&acc)[G], const 
 // instead of 3 per slot.  (A jump to the first slot of the run with fall-through from slot to slot would be cheaper
 // still, but the compiler structurises that switch into a state machine of 64-bit flags.)
 template <int VPL, int N>
-__device__ __forceinline__ void load_window(typename Vec<VPL>::T (&win)[NW], uint32_t u, __amdgpu_buffer_rsrc_t rs,
+__device__ __forceinline__ void load_window(typename Vec<VPL>::T (&win)[NW], wm_t u, __amdgpu_buffer_rsrc_t rs,
                                             int voff, unsigned rowoff, unsigned pix)
 {
     if constexpr (4 * N < NW) {
-        if (u & (0xFu << (4 * N))) {
+        if (u & ((wm_t)0xF << (4 * N))) {
             unsigned off = rowoff + (unsigned)(4 * N) * pix;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (4 * N + i < NW) {
-                    if (u & (1u << (4 * N + i))) win[4 * N + i] = Vec<VPL>::load(rs, voff, off);
+                    if (u & (kOne << (4 * N + i))) win[4 * N + i] = Vec<VPL>::load(rs, voff, off);
                     off += pix;
                 }
             }
@@ -151,21 +181,24 @@ struct Jobs {
 // blockIdx.x >> 3 = group of 4 rows inside the band (one row per wave), blockIdx.y = group of G columns,
 // blockIdx.z = (job, chunk of 64 * VPL disparities).  Dispatch order is x fastest, then y: inside its band an XCD
 // sweeps column group by column group.
+#ifndef CBCA_HWD_MINW
+#define CBCA_HWD_MINW 1
+#endif
 template <int VPL>
-__global__ __launch_bounds__(256) void cbca_hwd_kernel(const Jobs jobs, int Dp, int H, int W, int nchunks, int band_rows)
+__global__ __launch_bounds__(64 * CBCA_HWD_WPB, CBCA_HWD_MINW) void cbca_hwd_kernel(const Jobs jobs, int Dp, int H, int W, int nchunks, int band_rows)
 {
     typedef typename Vec<VPL>::T vf;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int y = (int)(blockIdx.x & 7) * band_rows + (int)(blockIdx.x >> 3) * 4 + wv;
+    const int y = (int)(blockIdx.x & 7) * band_rows + (int)(blockIdx.x >> 3) * CBCA_HWD_WPB + wv;
     if (y >= H) return;
     const int x0 = (int)blockIdx.y * G;
     const int job = (int)blockIdx.z / nchunks, chunk = (int)blockIdx.z - job * nchunks;
     const float *const in = job ? jobs.in[1] : jobs.in[0];
     float *const out = job ? jobs.out[1] : jobs.out[0];
     const Support *__restrict__ const sup = job ? jobs.sup[1] : jobs.sup[0];
-    const uint32_t *__restrict__ const wmask =
-        reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(sup) + wmask_plane_offset(H, W));
+    const wm_t *__restrict__ const wmask =
+        reinterpret_cast<const wm_t *>(reinterpret_cast<const char *>(sup) + wmask_plane_offset(H, W));
 
     const unsigned pix = (unsigned)Dp * 4u;                       // bytes between neighbouring pixels
     const int row0 = max(y - R, 0), row1 = min(y + R, H - 1);      // rows any arm of this group can reach
@@ -180,7 +213,8 @@ __global__ __launch_bounds__(256) void cbca_hwd_kernel(const Jobs jobs, int Dp, 
     // anchors: vertical arms and region sizes (plane 0), window masks of the anchor row.  The words of a group that
     // straddles the right edge are read (they lie inside the support buffer) but never used: their schedule is empty.
     const size_t p0 = (size_t)y * W + x0;
-    uint32_t aw[G], nxt[G];
+    uint32_t aw[G];
+    wm_t nxt[G];
 #pragma unroll
     for (int j = 0; j < G; ++j) {
         aw[j] = sup[p0 + j];
@@ -209,10 +243,10 @@ __global__ __launch_bounds__(256) void cbca_hwd_kernel(const Jobs jobs, int Dp, 
 
     int yq = y;
     for (int t = 0; t < nrows; ++t) {
-        uint32_t m[G], u = 0u;
+        wm_t m[G], u = 0;
 #pragma unroll
         for (int j = 0; j < G; ++j) {
-            m[j] = (sched[j] >> t) & 1u ? nxt[j] : 0u;
+            m[j] = (sched[j] >> t) & 1u ? nxt[j] : (wm_t)0;
             u |= m[j];
         }
         // slot k = column x0 - R + k; the offset may wrap below zero for slots left of the image, which no arm reaches
@@ -233,7 +267,7 @@ __global__ __launch_bounds__(256) void cbca_hwd_kernel(const Jobs jobs, int Dp, 
     for (int j = 0; j < G; ++j) {
         if (up[j] >= 0) {
             const float n = (float)sup_count(aw[j]);
-            const vf res = acc[j] / n;                             // pf:161
+            const vf res = Vec<VPL>::div(acc[j], n);                             // pf:161
             Vec<VPL>::store(res, rs_out, voff, (unsigned)j * pix);
         }
     }
@@ -254,7 +288,7 @@ static int launch(const Jobs &jobs, int D, int H, int W, hipStream_t s)
     const int ngroups = cdiv(W, G);
     MCCNN_REQUIRE(ngroups <= 65535 && nchunks * jobs.n <= 65535, MCCNN_E_UNSUPPORTED,
                   "mccnn_cbca_iter_hwd: %dx%dx%d exceeds the grid", W, H, D);
-    const dim3 grid(8 * (band_rows / 4), ngroups, nchunks * jobs.n), block(256);
+    const dim3 grid(8 * (band_rows / CBCA_HWD_WPB), ngroups, nchunks * jobs.n), block(64 * CBCA_HWD_WPB);
     if (vpl == 4)
         hipLaunchKernelGGL(cbca_hwd_kernel<4>, grid, block, 0, s, jobs, Dp, H, W, nchunks, band_rows);
     else

@@ -142,8 +142,8 @@ __global__ __launch_bounds__(256) void cross_count_kernel(Support *__restrict__ 
     reinterpret_cast<unsigned long long *>(base + emit_plane_offset(H, W))[p] =
         (((rbits - field + 0x800ull) >> 12) << 12) | field;
     // window mask of the pixel-major reference-order kernel (support.h)
-    reinterpret_cast<uint32_t *>(base + wmask_plane_offset(H, W))[p] =
-        (uint32_t)(((2ull << (left + right)) - 1ull) << (w % HWD_G + HWD_R - left));
+    reinterpret_cast<hwd_mask_t *>(base + wmask_plane_offset(H, W))[p] =
+        (hwd_mask_t)(((2ull << (left + right)) - 1ull) << (w % HWD_G + HWD_R - left));
 }
 
 // pf:637-655: explicit list, order (self, up.., down..) x (self, left.., right..), padded with (-1,-1)

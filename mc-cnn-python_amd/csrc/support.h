@@ -18,7 +18,7 @@ __host__ __device__ __forceinline__ int sup_count(uint32_t a) { return (int)(a >
 // planes private to the aggregation kernels.  Written by cross_count_kernel / cross_perm_kernel (cross_cbca.hip).
 //   hsum  [H][W] uint32, emit [H][W] uint64 : cbca_stream_kernel's ready-made LDS addresses / reciprocals
 //   perm  per 16 x 64 tile uint16[1024]      : cbca_ref4_kernel's lane order
-//   wmask [H][W] uint32                      : cbca_hwd_kernel's window masks (below)
+//   wmask [H][W] uint32 / uint64             : cbca_hwd_kernel's window masks (below)
 __host__ __device__ __forceinline__ size_t hsum_plane_offset(int H, int W) { return ((size_t)H * W * 4 + 15) & ~(size_t)15; }
 __host__ __device__ __forceinline__ size_t emit_plane_offset(int H, int W)
 {
@@ -41,18 +41,24 @@ __host__ __device__ __forceinline__ size_t perm_plane_bytes(int H, int W)
 // so the union of a row's loads is an OR, "pixel sits this row out" is a zero mask, and every step of a chain is one
 // scalar bit test - the walk costs the scalar unit ~3 instructions per pixel and row instead of ~25.
 #ifndef CBCA_HWD_G
-#define CBCA_HWD_G 4
+#define CBCA_HWD_G 6
 #endif
 constexpr int HWD_G = CBCA_HWD_G;
 constexpr int HWD_R = 13;
 constexpr int HWD_NW = HWD_G + 2 * HWD_R;
-static_assert(HWD_NW <= 32, "window masks are 32-bit words");
+static_assert(HWD_NW <= 64, "window masks are at most 64-bit words");
+template <bool WIDE> struct HwdMask { typedef uint32_t T; };
+template <> struct HwdMask<true> { typedef uint64_t T; };
+typedef HwdMask<(HWD_NW > 32)>::T hwd_mask_t;       // one bit per window slot
 __host__ __device__ __forceinline__ size_t wmask_plane_offset(int H, int W)
 {
     return (perm_plane_offset(H, W) + perm_plane_bytes(H, W) + 15) & ~(size_t)15;
 }
-// + 32: a wave reads the HWD_G words of its group in one scalar load, also where the group straddles the right edge
-__host__ __device__ __forceinline__ size_t wmask_plane_bytes(int H, int W) { return (size_t)H * W * 4 + 32; }
+// + 128: a wave reads the HWD_G words of its group in one scalar load, also where the group straddles the right edge
+__host__ __device__ __forceinline__ size_t wmask_plane_bytes(int H, int W)
+{
+    return (size_t)H * W * sizeof(hwd_mask_t) + 128;
+}
 
 // Host-side record of what mccnn_cross_arms last wrote where (cross_cbca.hip): refuses a support plane built for
 // another image size or with longer arms than the caller states; unknown pointers pass.

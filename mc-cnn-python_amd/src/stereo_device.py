@@ -509,11 +509,12 @@ class StereoMatcher(object):
     """The timed region of match.py:129-179 for one stereo pair, resident on one GPU.
 
     net: model.NET with weights loaded (kept resident; the reference re-restores per pair, pf:43).
-    cv_mode / cbca_order select the bit-exact or the fast variant of those two stages.
+    cv_mode / cbca_order select the bit-exact (default, like process_functional and match.py) or the fast,
+    tolerance-bounded variant of those two stages.
     """
 
-    def __init__(self, net, hp=None, cv_mode=hip.MCCNN_CV_EXACT, cbca_order=hip.MCCNN_CBCA_SEPARABLE,
-                 feature_tile_rows=None, extras=None, features="miopen"):
+    def __init__(self, net, hp=None, cv_mode=hip.MCCNN_CV_EXACT, cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER,
+                 feature_tile_rows=None, extras=None, features="miopen", layout="auto"):
         self.device = hip.require_device()
         self.net = net
         self.hp = dict(DEFAULT_HP)
@@ -528,6 +529,11 @@ class StereoMatcher(object):
         if features == "split_f16" and feature_tile_rows is not None:
             raise ValueError("row banding is implemented for the library convolutions only")
         self.features = features
+        # "auto": the bit-exact variant runs on pixel-major volumes (pixel_major()); "plane_major" keeps every stage
+        # on the reference's [D,H,W] layout (the round-2 kernels: cross-checks, and what the fast variant always uses)
+        if layout not in ("auto", "plane_major"):
+            raise ValueError("layout must be 'auto' or 'plane_major'")
+        self.layout = layout
         # opt-in departures from the reference (they change the output): the paper's rules it leaves out, and the
         # scalar promotion of the NumPy it was written for
         self.extras = dict(both_view_support=False, interpolation_directions=4, occlusion_from_left=False,
@@ -546,13 +552,10 @@ class StereoMatcher(object):
         ws = self._ws.get(key)
         if ws is None:
             dp = hwd_pitch(D)
-            n = H * W * dp
+            n = H * W * dp                        # >= D*H*W: every volume buffer can hold either layout
             dev = self.device
             ws = dict(
-                lcv=torch.empty((D, H, W), dtype=torch.float32, device=dev),
-                rcv=torch.empty((D, H, W), dtype=torch.float32, device=dev),
-                t1=torch.empty((n,), dtype=torch.float32, device=dev),
-                t2=torch.empty((n,), dtype=torch.float32, device=dev),
+                vol=[torch.empty((n,), dtype=torch.float32, device=dev) for _ in range(4)],
                 scratch=sgm_scratch(H, W, D, dev),
                 sup_l=support_buffer(H, W, dev), sup_r=support_buffer(H, W, dev),
                 status=torch.empty((H, W), dtype=torch.int32, device=dev),
@@ -563,9 +566,18 @@ class StereoMatcher(object):
             self._graphs = {}
         return ws
 
-    def match(self, left_image, right_image, ndisp, timer=_NO_TIMER, keep=None):
+    def pixel_major(self):
+        """True when the pair runs on pixel-major volumes from the first aggregation on: the bit-exact variant
+        (reference-order CBCA, arms <= 13, no two-view regions).  CBCA, SGM, WTA and sub-pixel then all work on
+        [H,W,Dp] and no layout change surrounds the SGM stage."""
+        return (self.layout == "auto" and self.cbca_order == hip.MCCNN_CBCA_REFERENCE_ORDER
+                and not self.extras["both_view_support"]
+                and int(self.hp["cbca_distance"]) <= 14)
+
+    def match(self, left_image, right_image, ndisp, timer=_NO_TIMER, keep=None, _static_out=False):
         """left/right: standardised float32 device tensors [H,W] (or [H,W,1]).  Returns the final left disparity
-        map [H,W] on the device.  `keep`, if a dict, receives intermediate device tensors (tests)."""
+        map [H,W] on the device (a fresh tensor; the matcher's workspace is reused by the next call).  `keep`, if a
+        dict, receives intermediate device tensors in the reference's [D,H,W] layout (tests)."""
         hp = self.hp
         L = left_image.reshape(left_image.shape[0], left_image.shape[1]).contiguous()
         R = right_image.reshape(right_image.shape[0], right_image.shape[1]).contiguous()
@@ -575,6 +587,10 @@ class StereoMatcher(object):
         dhw = (D, H, W)
         hwd = (H, W, hwd_pitch(D))
         nd, nh = D * H * W, H * W * hwd[2]
+        as_dhw = lambda buf: buf[:nd].view(dhw)       # noqa: E731
+        as_hwd = lambda buf: buf[:nh].view(hwd)       # noqa: E731
+        b0, b1, b2, b3 = ws["vol"]
+        sides = [hip.MCCNN_SIDE_LEFT, hip.MCCNN_SIDE_RIGHT]
 
         # The support arms depend on the images only: without per-stage timing they run on a side stream under the
         # conv stack (a latency-bound pair of small launches beside matrix-core work) and join before the first CBCA
@@ -595,7 +611,7 @@ class StereoMatcher(object):
         timer.stop()
 
         timer.start("cost_volume")
-        lcv, rcv = cost_volume(fl, fr, D, self.cv_mode, out=(ws["lcv"], ws["rcv"]))
+        lcv, rcv = cost_volume(fl, fr, D, self.cv_mode, out=(as_dhw(b0), as_dhw(b1)))
         timer.stop()
         del fl, fr
         if keep is not None:
@@ -609,57 +625,84 @@ class StereoMatcher(object):
             timer.stop()
 
         ex = self.extras
+        m = ws["maps"] if keep is None else torch.empty_like(ws["maps"])
+        if self.pixel_major():
+            # ---- bit-exact variant: pixel-major from here on ----
+            timer.start("cv_to_pixel_major")
+            lh, rh = dhw_to_hwd(lcv, as_hwd(b2)), dhw_to_hwd(rcv, as_hwd(b3))
+            timer.stop()
+            (lh, lt), (rh, rt) = cbca_hwd_pair(lh, as_hwd(b0), sup_l, rh, as_hwd(b1), sup_r, D,
+                                               hp["cbca_num_iterations1"], hp["cbca_distance"], timer)
+            if keep is not None:
+                keep["cbca1"] = (hwd_to_dhw(lh, D), hwd_to_dhw(rh, D))
+            sgm_average_hwd(L, R, [lh, rh], sides, D, hp["sgm_P1"], hp["sgm_P2"], hp["sgm_Q1"], hp["sgm_Q2"],
+                            hp["sgm_D"], hp["sgm_V"], ws["scratch"], timer)
+            if keep is not None:
+                keep["sgm"] = (hwd_to_dhw(lh, D), hwd_to_dhw(rh, D))
+            (lh, lt), (rh, rt) = cbca_hwd_pair(lh, lt, sup_l, rh, rt, sup_r, D, hp["cbca_num_iterations2"],
+                                               hp["cbca_distance"], timer)
+            if keep is not None:
+                keep["cbca2"] = (hwd_to_dhw(lh, D), hwd_to_dhw(rh, D))
+            timer.start("wta")
+            dl = wta_hwd(lh, D, out=m[0])
+            dr = wta_hwd(rh, D, out=m[1])
+            timer.stop()
+            sub = lambda di: subpixel_hwd(di, lh, D, out=m[3], numpy1_promotion=ex["numpy1_promotion"])   # noqa: E731
+        else:
+            def aggregate(vol, tmp, own, other, n, side):
+                if ex["both_view_support"]:
+                    return cbca_both_views(vol, tmp, own, other, n, hp["cbca_distance"], side, timer)
+                return cbca(vol, tmp, own, n, hp["cbca_distance"], self.cbca_order, timer)
 
-        def aggregate(vol, tmp, own, other, n, side):
-            if ex["both_view_support"]:
-                return cbca_both_views(vol, tmp, own, other, n, hp["cbca_distance"], side, timer)
-            return cbca(vol, tmp, own, n, hp["cbca_distance"], self.cbca_order, timer)
+            def aggregate_both(lcv, t1d, rcv, t2d, n):
+                # the separable kernel takes both views in one launch; the other variants run view by view
+                if not ex["both_view_support"] and self.cbca_order == hip.MCCNN_CBCA_SEPARABLE:
+                    return cbca_pair(lcv, t1d, sup_l, rcv, t2d, sup_r, n, hp["cbca_distance"], self.cbca_order, timer)
+                return (aggregate(lcv, t1d, sup_l, sup_r, n, hip.MCCNN_SIDE_LEFT),
+                        aggregate(rcv, t2d, sup_r, sup_l, n, hip.MCCNN_SIDE_RIGHT))
 
-        def aggregate_both(lcv, t1d, rcv, t2d, n):
-            # the separable kernel takes both views in one launch; the other variants run view by view
-            if not ex["both_view_support"] and self.cbca_order == hip.MCCNN_CBCA_SEPARABLE:
-                return cbca_pair(lcv, t1d, sup_l, rcv, t2d, sup_r, n, hp["cbca_distance"], self.cbca_order, timer)
-            return (aggregate(lcv, t1d, sup_l, sup_r, n, hip.MCCNN_SIDE_LEFT),
-                    aggregate(rcv, t2d, sup_r, sup_l, n, hip.MCCNN_SIDE_RIGHT))
+            (lcv, t1d), (rcv, t2d) = aggregate_both(lcv, as_dhw(b2), rcv, as_dhw(b3), hp["cbca_num_iterations1"])
+            if keep is not None:
+                keep["cbca1"] = (lcv.clone(), rcv.clone())
 
-        t1d, t2d = ws["t1"][:nd].view(dhw), ws["t2"][:nd].view(dhw)
-        (lcv, t1d), (rcv, t2d) = aggregate_both(lcv, t1d, rcv, t2d, hp["cbca_num_iterations1"])
-        if keep is not None:
-            keep["cbca1"] = (lcv.clone(), rcv.clone())
+            # SGM on pixel-major copies in the spare ping-pong buffers (every buffer holds either layout)
+            lh, rh = t1d.reshape(-1), t2d.reshape(-1)
+            lh = next(as_hwd(b) for b in ws["vol"] if b.data_ptr() == lh.data_ptr())
+            rh = next(as_hwd(b) for b in ws["vol"] if b.data_ptr() == rh.data_ptr())
+            sgm_average_from_dhw(L, R, [lcv, rcv], [lh, rh], sides, D, hp["sgm_P1"], hp["sgm_P2"], hp["sgm_Q1"],
+                                 hp["sgm_Q2"], hp["sgm_D"], hp["sgm_V"], ws["scratch"], timer)
+            timer.start("hwd_to_dhw")
+            hwd_to_dhw(lh, D, lcv)
+            hwd_to_dhw(rh, D, rcv)
+            timer.stop()
+            if keep is not None:
+                keep["sgm"] = (lcv.clone(), rcv.clone())
 
-        # SGM on pixel-major copies; t1d/t2d are the spare buffers (possibly swapped with ws[lcv/rcv] by the ping-pong)
-        lh, rh = self._as_hwd(t1d, ws, hwd, nh), self._as_hwd(t2d, ws, hwd, nh)
-        sgm_average_from_dhw(L, R, [lcv, rcv], [lh, rh], [hip.MCCNN_SIDE_LEFT, hip.MCCNN_SIDE_RIGHT], D, hp["sgm_P1"],
-                             hp["sgm_P2"], hp["sgm_Q1"], hp["sgm_Q2"], hp["sgm_D"], hp["sgm_V"], ws["scratch"], timer)
-        timer.start("hwd_to_dhw")
-        hwd_to_dhw(lh, D, lcv)
-        hwd_to_dhw(rh, D, rcv)
-        timer.stop()
-        if keep is not None:
-            keep["sgm"] = (lcv.clone(), rcv.clone())
-
-        (lcv, t1d), (rcv, t2d) = aggregate_both(lcv, t1d, rcv, t2d, hp["cbca_num_iterations2"])
-        if keep is not None:
-            keep["cbca2"] = (lcv.clone(), rcv.clone())
+            (lcv, t1d), (rcv, t2d) = aggregate_both(lcv, t1d, rcv, t2d, hp["cbca_num_iterations2"])
+            if keep is not None:
+                keep["cbca2"] = (lcv.clone(), rcv.clone())
+            timer.start("wta")
+            dl = wta(lcv, out=m[0])
+            dr = wta(rcv, out=m[1])
+            timer.stop()
+            sub = lambda di: subpixel(di, lcv, out=m[3], numpy1_promotion=ex["numpy1_promotion"])   # noqa: E731
 
         # per-pair maps live in the workspace unless the caller keeps intermediates (tests): a pair then allocates
         # nothing but the conv activations and never blocks the host
-        m = ws["maps"] if keep is None else torch.empty_like(ws["maps"])
-        timer.start("wta")
-        dl = wta(lcv, out=m[0])
-        dr = wta(rcv, out=m[1])
-        timer.stop()
         timer.start("post")
         st = lr_status(dl, dr, D, out=ws["status"] if keep is None else None)
         di = interpolate(dl, st, out=m[2], directions=ex["interpolation_directions"],
                          occlusion_from_left=ex["occlusion_from_left"])
-        ds = subpixel(di, lcv, out=m[3], numpy1_promotion=ex["numpy1_promotion"])
+        ds = sub(di)
         dm = median(ds, 5, 5, out=m[4])
         db = bilateral(L, dm, 5, 5, 0, hp["blur_sigma"], hp["blur_threshold"], out=m[5])
         timer.stop()
         if keep is not None:
             keep.update(wta=(dl, dr), status=st, interp=di, subpixel=ds, median=dm, bilateral=db)
-        return db
+            return db
+        # the workspace map is overwritten by the next pair: hand out a copy unless the caller (match_graph) wants
+        # the static buffer
+        return db if _static_out else db.clone()
 
     def match_graph(self, left_image, right_image, ndisp):
         """match() replayed as ONE hipGraph launch: the ~75 kernel launches of a pair are captured once per image
@@ -683,7 +726,7 @@ class StereoMatcher(object):
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                out = self.match(sl, sr, ndisp)
+                out = self.match(sl, sr, ndisp, _static_out=True)
             g = (graph, sl, sr, out)
             self._graphs[key] = g
         graph, sl, sr, out = g
@@ -691,15 +734,3 @@ class StereoMatcher(object):
         sr.copy_(R)
         graph.replay()
         return out
-
-    @staticmethod
-    def _as_hwd(spare_dhw, ws, hwd, nh):
-        """The spare ping-pong buffer viewed as an HWD volume (both live in the t1/t2 or lcv/rcv allocations; the
-        t buffers are sized for the HWD pitch, the cv buffers only when Dp == D)."""
-        base = spare_dhw.reshape(-1)
-        for name in ("t1", "t2"):
-            if base.data_ptr() == ws[name].data_ptr():
-                return ws[name][:nh].view(hwd)
-        if nh == base.numel():
-            return base.view(hwd)
-        return torch.empty(hwd, dtype=torch.float32, device=base.device)
