@@ -47,6 +47,9 @@ constexpr wm_t kOne = 1;
 #ifndef CBCA_HWD_NTS
 #define CBCA_HWD_NTS 2                 // aux bits of the result stores (2 = non-temporal)
 #endif
+#ifndef CBCA_HWD_ABL
+#define CBCA_HWD_ABL 0                 // timing-only ablations (wrong results): 1 no adds, 2 no window loads, 3 neither
+#endif
 #ifndef CBCA_HWD_BLOCK4
 #define CBCA_HWD_BLOCK4 0
 #endif
@@ -72,7 +75,14 @@ template <> struct Vec<4> {
     static __device__ __forceinline__ T zero() { T v = {0.f, 0.f, 0.f, 0.f}; return v; }
     // a += w as four v_add_f32: this file is built with -fno-slp-vectorize (Makefile), because clang otherwise packs the
     // four adds into two v_pk_add_f32, which gfx950 issues at a fraction of the plain rate - same IEEE sums either way.
-    static __device__ __forceinline__ void add(T &a, const T &w) { a.x += w.x; a.y += w.y; a.z += w.z; a.w += w.w; }
+    static __device__ __forceinline__ void add(T &a, const T &w)
+    {
+#if (CBCA_HWD_ABL & 1)
+        a.x += w.x;                        // one add instead of four
+#else
+        a.x += w.x; a.y += w.y; a.z += w.z; a.w += w.w;
+#endif
+    }
     static __device__ __forceinline__ T div(const T &a, float n) { T v = {a.x / n, a.y / n, a.z / n, a.w / n}; return v; }
 };
 template <> struct Vec<2> {
@@ -160,7 +170,14 @@ __device__ __forceinline__ void load_window(typename Vec<VPL>::T (&win)[NW], wm_
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (4 * N + i < NW) {
+#if (CBCA_HWD_ABL & 2)
+                    if (u & (kOne << (4 * N + i))) {
+                        win[4 * N + i] = Vec<VPL>::zero();
+                        win[4 * N + i].x = __int_as_float(voff + (int)off);   // a value the compiler cannot fold
+                    }
+#else
                     if (u & (kOne << (4 * N + i))) win[4 * N + i] = Vec<VPL>::load(rs, voff, off);
+#endif
                     off += pix;
                 }
             }

@@ -12,7 +12,9 @@ There is no CPU fallback: without a HIP device or without the built library ever
 Options the reference does not have (module attributes; the DEFAULTS are the bit-exact variants, so that a drop-in
 user gets the reference's numbers - the fast ones are opt-in and only tolerance-bounded):
     COST_VOLUME_MODE  "exact" (NumPy summation order, bit-exact, default) | "mfma" (matrix cores, <= 2e-6 abs)
-    CBCA_ORDER        "reference" (flat list order, bit-exact, default) | "separable" (fast, <= 1e-6 abs per iteration)
+    CBCA_ORDER        "reference" (flat list order, bit-exact, default: the pixel-major kernel, mccnn_cbca_iter_hwd)
+                      | "reference_plane_major" (the same sums by the plane-major kernel of mccnn_cbca_iter - slower;
+                        also what distances > 14 fall back to) | "separable" (fast, <= 1e-6 abs per iteration)
 Opt-in departures from the reference's results (defaults reproduce it):
     CBCA_BOTH_VIEWS          False | True  - the paper's support regions intersected with the other view's (pf:122-144
                                              names it and skips it as impractical; pf:661-729 is its dead attempt)
@@ -37,7 +39,8 @@ OCCLUSION_FROM_LEFT = False
 NUMPY1_PROMOTION = False
 
 _CV_MODES = {"exact": hip.MCCNN_CV_EXACT, "mfma": hip.MCCNN_CV_MFMA}
-_CBCA_ORDERS = {"separable": hip.MCCNN_CBCA_SEPARABLE, "reference": hip.MCCNN_CBCA_REFERENCE_ORDER}
+_CBCA_ORDERS = {"separable": hip.MCCNN_CBCA_SEPARABLE, "reference": hip.MCCNN_CBCA_REFERENCE_ORDER,
+                "reference_plane_major": hip.MCCNN_CBCA_REFERENCE_ORDER}
 
 __all__ = ["compute_features", "compute_cost_volume", "cost_volume_aggregation", "SGM_average",
            "disparity_prediction", "interpolation", "subpixel_enhance", "median_filter", "bilateral_filter",
@@ -120,6 +123,14 @@ def cost_volume_aggregation(left_image, right_image, left_cost_volume, right_cos
         if CBCA_BOTH_VIEWS:
             res, _spare = sd.cbca_both_views(v, torch.empty_like(v), supports[k], supports[1 - k], int(max_average_time),
                                              int(distance_threshold), hip.MCCNN_SIDE_LEFT if k == 0 else hip.MCCNN_SIDE_RIGHT)
+        elif CBCA_ORDER == "reference" and int(distance_threshold) <= 14:
+            # the reference's summation order on a pixel-major copy (disparities on lanes): bit-identical to the
+            # plane-major reference-order kernel, several times faster
+            D = v.shape[0]
+            hv = sd.dhw_to_hwd(v)
+            hres, _spare = sd.cbca_hwd(hv, torch.empty_like(hv), supports[k], D, int(max_average_time),
+                                       int(distance_threshold))
+            res = sd.hwd_to_dhw(hres, D)
         else:
             res, _spare = sd.cbca(v, torch.empty_like(v), supports[k], int(max_average_time), int(distance_threshold),
                                   _CBCA_ORDERS[CBCA_ORDER])

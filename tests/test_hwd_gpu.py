@@ -1,0 +1,196 @@
+"""GPU: the pixel-major ("HWD", [H][W][Dp]) kernels of the bit-exact variant - mccnn_cbca_iter_hwd(_pair),
+mccnn_wta_hwd, mccnn_subpixel_hwd - called through the C ABI, against the reference's golden vectors, the CPU oracle
+on ragged shapes, and their plane-major counterparts.  Everything here is bit-exact (integer/index work and float32
+sums in the reference's own order)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_bits, hp_of
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sd():
+    import _hipabi
+    _hipabi.require_device()
+    import stereo_device
+    return stereo_device
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _agg(sd, vol_dhw, image, tau, dist, n):
+    """n reference-order iterations through the pixel-major kernel; numpy [D,H,W] in and out."""
+    v = dev(vol_dhw)
+    D = v.shape[0]
+    sup = sd.cross_arms(dev(image.reshape(image.shape[0], image.shape[1])), tau, dist)
+    hv = sd.dhw_to_hwd(v)
+    res, _ = sd.cbca_hwd(hv, torch.full_like(hv, float("nan")), sup, D, n, dist)
+    return sd.hwd_to_dhw(res, D).cpu().numpy()
+
+
+def test_golden_cbca_pixel_major_bit_exact(sd, golden_cases):
+    """pf:149-163 as the reference itself computed it: 1, it1 (=2) and it2 (=16) iterations, both views."""
+    for name, g in golden_cases:
+        hp = hp_of(g)
+        tau, dist = hp["cbca_intensity"], int(hp["cbca_distance"])
+        for side, img in (("l", g["left"]), ("r", g["right"])):
+            assert_bits(_agg(sd, g["cv_" + side], img, tau, dist, 1), g["cbca1it_" + side], name + " 1 iteration " + side)
+            assert_bits(_agg(sd, g["cv_" + side], img, tau, dist, int(hp["it1"])), g["cbca1_" + side], name + " it1 " + side)
+            assert_bits(_agg(sd, g["sgm_" + side], img, tau, dist, int(hp["it2"])), g["cbca2_" + side], name + " it2 " + side)
+
+
+@pytest.mark.parametrize("H,W,D", [(45, 100, 20), (64, 127, 33), (100, 70, 8), (7, 5, 3), (30, 13, 2), (21, 64, 130),
+                                   (16, 75, 256), (12, 50, 400), (3, 200, 64)])
+def test_oracle_cbca_pixel_major_ragged_shapes(sd, H, W, D):
+    """Widths that are not a multiple of the pixel group (or smaller than one), heights below the arm limit, one and two
+    256-disparity chunks, D not a multiple of 4: against the CPU checker, 2 iterations."""
+    import oracle as o
+    import synthetic
+    rng = np.random.default_rng(H * 1000 + W)
+    L, R, _, _, _ = synthetic.make_pair(H, W, min(16, W - 2), seed=W)
+    vl = (rng.random((D, H, W), dtype=np.float32) * 3 - 2).astype(np.float32)
+    vr = (rng.random((D, H, W), dtype=np.float32) * 3 - 2).astype(np.float32)
+    ol, orr = o.cost_volume_aggregation(L, R, vl, vr, 0.02, 14, 2)
+    assert_bits(_agg(sd, vl, L, 0.02, 14, 2), ol, "left")
+    assert_bits(_agg(sd, vr, R, 0.02, 14, 2), orr, "right")
+
+
+def test_oracle_cbca_pixel_major_long_arms_and_other_distances(sd):
+    """Flat image (every arm at the limit: 27 x 27 regions, every window slot in use), a striped one, and distance
+    thresholds below the default."""
+    import oracle as o
+    rng = np.random.default_rng(1)
+    H, W, D = 50, 90, 5
+    L = np.zeros((H, W, 1), np.float32)
+    R = np.zeros((H, W, 1), np.float32)
+    R[:, ::7] = 1.0
+    vl = rng.standard_normal((D, H, W)).astype(np.float32)
+    vr = rng.standard_normal((D, H, W)).astype(np.float32)
+    for dist in (14, 6, 2, 1):
+        ol, orr = o.cost_volume_aggregation(L, R, vl, vr, 0.02, dist, 2)
+        assert_bits(_agg(sd, vl, L, 0.02, dist, 2), ol, "flat image, distance %d" % dist)
+        assert_bits(_agg(sd, vr, R, 0.02, dist, 2), orr, "striped image, distance %d" % dist)
+
+
+def test_cbca_pixel_major_special_values(sd):
+    """inf / nan / signed zeros travel through the running sum exactly as float32 addition defines (the plane-major
+    reference-order kernel is the witness: same additions in the same order)."""
+    import _hipabi as hip
+    rng = np.random.default_rng(3)
+    H, W, D = 40, 66, 9
+    img = dev(np.floor(rng.random((H, W), dtype=np.float32) * 3) * np.float32(0.01))
+    sup = sd.cross_arms(img, 0.02, 14)
+    v = rng.standard_normal((D, H, W)).astype(np.float32)
+    v[0, 5, 7] = np.inf
+    v[1, 9, 30] = -np.inf
+    v[2, 20, 40] = np.nan
+    v[3] = -0.0
+    v[4, ::2] = 0.0
+    vd = dev(v)
+    ref, _ = sd.cbca(vd.clone(), torch.empty_like(vd), sup, 2, 14, hip.MCCNN_CBCA_REFERENCE_ORDER)
+    hv = sd.dhw_to_hwd(vd)
+    got, _ = sd.cbca_hwd(hv, torch.empty_like(hv), sup, D, 2, 14)
+    a, b = sd.hwd_to_dhw(got, D).cpu().numpy(), ref.cpu().numpy()
+    assert np.array_equal(a.view(np.uint32) | (np.isnan(a) * 0xFFFFFFFF).astype(np.uint32),
+                          b.view(np.uint32) | (np.isnan(b) * 0xFFFFFFFF).astype(np.uint32))
+
+
+@pytest.mark.parametrize("H,W,D,iters", [(70, 300, 5, 1), (40, 33, 1, 2), (64, 100, 300, 3)])
+def test_cbca_pixel_major_pair_launch_equals_single_launches(sd, H, W, D, iters):
+    import synthetic
+    L, R, _, _, _ = synthetic.make_pair(H, W, min(16, W - 2), seed=11)
+    sl, sr = sd.cross_arms_pair(dev(L[:, :, 0]), dev(R[:, :, 0]), 0.02, 14)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    Dp = sd.hwd_pitch(D)
+    a = torch.rand((H, W, Dp), device="cuda", generator=g) - 0.5
+    b = torch.rand((H, W, Dp), device="cuda", generator=g) - 0.5
+    (pl, _), (pr, _) = sd.cbca_hwd_pair(a.clone(), torch.empty_like(a), sl, b.clone(), torch.empty_like(b), sr, D, iters, 14)
+    ql, _ = sd.cbca_hwd(a.clone(), torch.empty_like(a), sl, D, iters, 14)
+    qr, _ = sd.cbca_hwd(b.clone(), torch.empty_like(b), sr, D, iters, 14)
+    assert torch.equal(pl[:, :, :D], ql[:, :, :D]) and torch.equal(pr[:, :, :D], qr[:, :, :D])
+
+
+def test_golden_wta_and_subpixel_pixel_major(sd, golden_cases):
+    for name, g in golden_cases:
+        for side in ("l", "r"):
+            v = dev(g["cbca2_" + side])
+            D = v.shape[0]
+            assert_bits(sd.wta_hwd(sd.dhw_to_hwd(v), D).cpu().numpy(), g["wta_" + side], name + " wta " + side)
+        v = dev(g["cbca2_l"])
+        D = v.shape[0]
+        assert_bits(sd.subpixel_hwd(dev(g["interp"]), sd.dhw_to_hwd(v), D).cpu().numpy(), g["subpixel"], name + " subpixel")
+
+
+@pytest.mark.parametrize("H,W,D", [(30, 50, 12), (17, 33, 70), (9, 40, 256), (8, 21, 401), (5, 7, 2)])
+def test_wta_subpixel_pixel_major_ties_nan_inf(sd, H, W, D):
+    """Ties (lowest index wins, also across lanes and across 256-disparity groups), all-NaN / all-inf pixels (-1),
+    NaN and inf among finite costs, zero denominators in the parabola: identical to the plane-major kernels, which are
+    pinned against the reference's golden vectors and the oracle."""
+    rng = np.random.default_rng(D)
+    v = np.round(rng.standard_normal((D, H, W)).astype(np.float32) * 2) / 2      # many exact ties
+    v[:, 0, 0] = np.nan
+    v[:, 0, 1] = np.inf
+    v[:, 1, 2] = 1.0                          # all equal: index 0
+    v[D // 2, 2, 3] = np.nan
+    v[:, 2, 4] = -np.inf                      # -inf everywhere: index 0
+    v[D - 1, 3, 5] = -100.0                   # minimum in the last disparity
+    if D > 256:
+        v[:, 4, 6] = 0.0
+        v[[3, 300], 4, 6] = -7.0              # tie across the two disparity groups: 3 wins
+    vd = dev(v)
+    hv = sd.dhw_to_hwd(vd)
+    w1, w2 = sd.wta(vd), sd.wta_hwd(hv, D)
+    assert torch.equal(w1, w2)
+    assert float(w2[0, 0]) == -1.0 and float(w2[0, 1]) == -1.0 and float(w2[1, 2]) == 0.0 and float(w2[3, 5]) == D - 1
+    d = (w1.clamp(min=0) + 0.5 * (torch.rand_like(w1) > 0.5)).contiguous()
+    for promo in (False, True):
+        s1 = sd.subpixel(d, vd, numpy1_promotion=promo)
+        s2 = sd.subpixel_hwd(d, hv, D, numpy1_promotion=promo)
+        assert torch.equal(torch.nan_to_num(s1, nan=12345.0), torch.nan_to_num(s2, nan=12345.0))
+
+
+def test_pixel_major_abi_error_behaviour(sd):
+    import _hipabi as hip
+    lib = hip.load()
+    H, W, D = 8, 16, 4
+    sup = sd.cross_arms(torch.zeros((H, W), device="cuda"), 0.02, 14)
+    a = torch.zeros((H, W, 4), device="cuda")
+    b = torch.zeros_like(a)
+    st = hip.stream()
+    assert lib.mccnn_cbca_iter_hwd(hip.ptr(a), hip.ptr(a), hip.ptr(sup), D, H, W, 14, st) == hip.MCCNN_E_INVALID
+    assert lib.mccnn_cbca_iter_hwd(hip.ptr(a), hip.ptr(b), hip.ptr(sup), D, H, W, 15, st) == hip.MCCNN_E_UNSUPPORTED
+    assert b"L=15" in lib.mccnn_last_error_string()
+    assert lib.mccnn_cbca_iter_hwd(None, hip.ptr(b), hip.ptr(sup), D, H, W, 14, st) == hip.MCCNN_E_INVALID
+    assert lib.mccnn_cbca_iter_hwd(hip.ptr(a), hip.ptr(b), hip.ptr(sup), D, H + 1, W, 14, st) == hip.MCCNN_E_INVALID  # other image
+    assert lib.mccnn_cbca_iter_hwd_pair(hip.ptr(a), hip.ptr(b), hip.ptr(sup), hip.ptr(a), hip.ptr(b), hip.ptr(sup), D, H,
+                                        W, 14, st) == hip.MCCNN_E_INVALID                                            # aliasing
+    assert lib.mccnn_wta_hwd(hip.ptr(a), 0, H, W, hip.ptr(b), st) == hip.MCCNN_E_INVALID
+    assert lib.mccnn_subpixel_hwd(None, hip.ptr(a), D, H, W, 0, hip.ptr(b), st) == hip.MCCNN_E_INVALID
+    assert lib.mccnn_cbca_iter_hwd(hip.ptr(a), hip.ptr(b), hip.ptr(sup), D, H, W, 14, st) == 0
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3"])
+def test_full_size_pixel_major_equals_plane_major(sd, cfg):
+    """One reference-order iteration at BASELINE's full sizes (750x500x256: one 256-disparity chunk with every lane in
+    use; 1242x375x192: a partial chunk, 207 pixel groups per row) on both kernels: bit-identical volumes, hence the
+    same WTA map."""
+    import _hipabi as hip
+    import synthetic
+    from bench import CONFIGS
+    H, W, D = CONFIGS[cfg]
+    L = synthetic.make_pair(H, W, D, seed=100)[0]
+    sup = sd.cross_arms(dev(L[:, :, 0]), 0.02, 14)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    v = -torch.rand((D, H, W), device="cuda", generator=g) * 50
+    ref, _ = sd.cbca(v.clone(), torch.empty_like(v), sup, 1, 14, hip.MCCNN_CBCA_REFERENCE_ORDER)
+    hv = sd.dhw_to_hwd(v)
+    got, _ = sd.cbca_hwd(hv, torch.empty_like(hv), sup, D, 1, 14)
+    assert torch.equal(sd.hwd_to_dhw(got, D), ref)
+    assert torch.equal(sd.wta_hwd(got, D), sd.wta(ref))

@@ -76,8 +76,11 @@ def test_golden_cross_region(pf, sd, golden_cases):
             assert np.array_equal(num, g["region_num_l"])
 
 
-def test_golden_cbca_reference_order_bit_exact(pf, golden_cases):
-    pf.CBCA_ORDER = "reference"
+@pytest.mark.parametrize("order", ["reference", "reference_plane_major"])
+def test_golden_cbca_reference_order_bit_exact(pf, golden_cases, order):
+    """Both kernels that keep the reference's summation order: the pixel-major one behind the drop-in default and the
+    plane-major one (round 2; still what distances > 14 use)."""
+    pf.CBCA_ORDER = order
     try:
         for name, g in golden_cases:
             hp = hp_of(g)
