@@ -24,6 +24,20 @@ int check_launch(const char *what)
     return (int)e;
 }
 
+int device_cus8()
+{
+    static int cache[64] = {0};   // benign race: every thread computes the same value
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cache[dev] == 0) {
+        int c = 0;
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+        c &= ~7;
+        cache[dev] = c < 8 ? 8 : c;
+    }
+    return cache[dev];
+}
+
 }  // namespace mccnn
 
 extern "C" int mccnn_version(void) { return MCCNN_ABI_VERSION; }

@@ -19,6 +19,10 @@ int check_launch(const char *what);
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Compute units of the CURRENT device, rounded down to whole groups of 8 (one CU of every XCD), never below 8;
+// looked up per device (a process may drive several) and remembered.
+int device_cus8();
+
 #define MCCNN_REQUIRE(cond, code, ...)        \
     do {                                      \
         if (!(cond)) {                        \

@@ -456,13 +456,7 @@ extern "C" int mccnn_conv3x3_split(const void *in, const void *packed_weights, c
     const int tiles_x = cdiv(Wo, TW), tiles_y = cdiv(Ho, TH);
     const long total = (long)tiles_x * tiles_y * N;
     MCCNN_REQUIRE(total <= 0x7fffffffL, MCCNN_E_UNSUPPORTED, "mccnn_conv3x3_split: too many tiles");
-    static const int cus = [] {
-        int dev = 0, c = 256;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0)
-            c = 256;
-        return c & ~7;
-    }();
+    const int cus = device_cus8();
     const long slots = (long)cus * (LDS_BYTES <= 80 * 1024 ? 2 : 1);     // resident workgroups
     const int grid = (int)(total < slots ? total : slots);
     const float inv = 1.f / (weight_scale * act_scale);

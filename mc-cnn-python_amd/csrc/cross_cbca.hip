@@ -862,14 +862,7 @@ static int launch_cbca_stream(const StreamJobs &jobs, int D, int H, int W, hipSt
     // remainder is cut into row chunks (each re-stages 2R halo rows, never shorter than 64 rows) so that it fills the
     // chip too - e.g. 750x500x256: 384 items on 256 CUs = 256 full-height workgroups + 128 items in two halves,
     // 526 + 276 staged rows per CU instead of 2 x 526 (one chunk) or 3 x 276 (everything in halves).
-    static const int slots = [] {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            cus = 256;
-        cus = (2 / PPW) * (cus > 0 ? cus : 256);
-        return cus & ~7;                         // groups of 8: the two parts of the launch keep their XCD phase
-    }();
+    const int slots = (2 / PPW) * device_cus8();   // groups of 8: the two parts of the launch keep their XCD phase
     const int DG = cdiv(D, PPW);                 // plane groups
     const long items = (long)nstrips * DG * jobs.n;
     const long nfull = slots > 0 ? items / slots * slots : 0;

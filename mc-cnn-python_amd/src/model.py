@@ -16,10 +16,10 @@ import math
 import os
 
 # MIOpen times every applicable solver the first time it meets a convolution shape; its reference "naive" direct
-# convolutions take ~150 ms per call at image size and never win - leaving them out of the search saves ~6 s per
-# process (forward) and more with the backward passes of training.  The user's own setting, if any, is kept.
-for _v in ("FWD", "BWD", "WRW"):
-    os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + _v, "0")
+# FORWARD convolutions take ~150 ms per call at image size and never win - leaving them out of the search saves ~6 s
+# per process.  Only the forward solver is touched (the backward / weight-gradient fallbacks of training stay
+# available), and the user's own setting, if any, is kept.
+os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "0")
 
 import numpy as np
 import torch
@@ -173,6 +173,14 @@ class NET(object):
         if cache is None or cache[0] != key:
             cache = (key, [stereo_device.conv3x3_split_pack(w) for w in self.weights[1:]])
             self._split_cache = cache
+            # Range check, once per weight set: the split records saturate at |x| = 65504 / act_scale (256 -> 255.9)
+            # and nothing downstream would notice.  A probe image of standardised-intensity range through the float32
+            # stack must stay a factor 4 below that at every layer (the trained checkpoint peaks at ~6).
+            with torch.no_grad():
+                g = torch.Generator().manual_seed(1)
+                probe = (torch.randn((1, 1, 48, 48), generator=g) * 2.0).clamp(-6, 6).to(self.device)
+                peak = max(float(o.abs().max()) for o in self._convs_nchw(probe))
+            self._split_range_ok = peak < 0.25 * 65504.0 / stereo_device.SPLIT_ACT_SCALE
         return cache[1]
 
     def features_pair_hwc_split(self, left_hw, right_hw):
@@ -180,19 +188,38 @@ class NET(object):
         MFMA products per multiply, float32 accumulation - as close to a float64 evaluation as the library path, not
         bit-identical to it (opt-in: StereoMatcher(features="split_f16"), match.py --fast).  Needs the 64-map 3x3
         topology with at least two layers; activations must stay below 65504 / 256 in magnitude."""
+        import warnings
         import stereo_device
         pad = (self.input_patch_size - 1) // 2
         assert pad == self.num_conv_layers * (self.conv_kernel_size - 1) // 2
         if self.conv_kernel_size != 3 or self.num_conv_feature_maps != 64 or self.num_conv_layers < 2:
             raise ValueError("the split-operand feature kernels are built for >= 2 layers of 64 maps, 3x3")
         packed = self._split_weights()
-        pair = torch.stack((left_hw, right_hw)).contiguous()
-        x = stereo_device.conv1_split(pair, self.weights[0].detach().contiguous(), self.biases[0].detach(), pad)
+        if not self._split_range_ok:
+            warnings.warn("split-operand features: this weight set drives activations beyond the f16 range of the "
+                          "stored records (|x| < %.0f); using the float32 library convolutions instead"
+                          % (65504.0 / stereo_device.SPLIT_ACT_SCALE))
+            return self.features_pair_hwc(left_hw, right_hw)
+        H, W = left_hw.shape
+        # the kernels address their records with 32-bit byte offsets: 256 B per padded pixel, both views in one batch
+        limit = 0x7ffffff0 // 256
+        padded = (H + 2 * pad - 2) * (W + 2 * pad - 2)
+        if padded > limit:
+            rows = max(64, (limit // (W + 2 * pad)) // 2)
+            warnings.warn("split-operand features: a %dx%d view exceeds the kernels' 32-bit record offsets; using the "
+                          "float32 library convolutions in bands of %d rows instead" % (W, H, rows))
+            return self.features_pair_hwc(left_hw, right_hw, tile_rows=rows)
+        batches = [torch.stack((left_hw, right_hw)).contiguous()] if 2 * padded <= limit else \
+            [left_hw[None].contiguous(), right_hw[None].contiguous()]          # too big as a pair: view by view
+        outs = []
         nl = self.num_conv_layers
-        for k in range(1, nl):
-            pk, ws = packed[k - 1]
-            x = stereo_device.conv3x3_split(x, pk, ws, self.biases[k].detach(), last=(k == nl - 1))
-        return x[0], x[1]
+        for views in batches:
+            x = stereo_device.conv1_split(views, self.weights[0].detach().contiguous(), self.biases[0].detach(), pad)
+            for k in range(1, nl):
+                pk, ws = packed[k - 1]
+                x = stereo_device.conv3x3_split(x, pk, ws, self.biases[k].detach(), last=(k == nl - 1))
+            outs += [x[i] for i in range(x.shape[0])]
+        return outs[0], outs[1]
 
     def features_pair_hwc(self, left_hw, right_hw, tile_rows=None):
         """Both views through the shared-weight stack as one batch of two (the Siamese towers are the same weights,

@@ -12,6 +12,10 @@ What the reference's graph does (train.py:71-106) and what happens here:
   * validation loss over val.txt every --val_freq epochs (:182-197); a checkpoint every --save_freq epochs (:176-180).
 Checkpoints are `.npz` files (conv<k>/weights HWIO, conv<k>/biases, plus the momentum slots) named
 `model_epoch<N>.ckpt.npz`; match.py's --resume and NET.restore read them (and the reference's TensorFlow bundles).
+Differences from the reference a maintainer should know: checkpoints are written as `.npz` only (match.py / train.py of
+THIS package read them and the reference's TensorFlow bundles, incl. the Momentum slots on --resume; the reference
+cannot read the .npz - one-way compatibility); the logged hinge_loss is the loss of the batch BEFORE its update (the
+reference re-evaluates the graph after the step, train.py:169-173); the patch sampler's RNG state is not checkpointed.
 TensorBoard is not in this image: the two scalars the reference logs (hinge_loss, val_hinge_loss) go to
 `<tensorboard_dir>/scalars.jsonl`, one JSON object per point with the reference's step numbering.
 Multi-GPU (not in the reference): under torchrun every rank draws its own batches and the gradients are averaged with
@@ -26,7 +30,9 @@ import numpy as np
 
 parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter,
                                  description="training of the MC-CNN matching network (fast architecture)")
-parser.add_argument("-g", "--gpu", type=str, default="0", help="index of the GPU to train on (ignored under torchrun)")
+parser.add_argument("-g", "--gpu", type=str, default="0",
+                    help="index of the GPU to train on (when not given, a HIP_VISIBLE_DEVICES already in the environment "
+                         "stands; ignored under torchrun)")
 parser.add_argument("-ps", "--patch_size", type=int, default=11, help="side of the square training patches")
 parser.add_argument("-bs", "--batch_size", type=int, default=128, help="patch triplets per mini-batch")
 parser.add_argument("-mr", "--margin", type=float, default=0.2, help="margin of the hinge loss")
@@ -109,15 +115,20 @@ class Trainer(object):
             for k, (w, b) in enumerate(layers):
                 self.net.weights[k].copy_(torch.from_numpy(np.ascontiguousarray(np.transpose(w, (3, 2, 0, 1)))))
                 self.net.biases[k].copy_(torch.from_numpy(np.ascontiguousarray(b)))
+        # the optimizer's momentum slots, as saver.restore brings them back in the reference (train.py:141-143):
+        # from this script's .npz, or from the "<var>/Momentum" tensors of a TensorFlow bundle
         if os.path.isfile(path) and path.endswith(".npz"):
             z = np.load(path)
-            for k in range(self.net.num_conv_layers):
-                for name, p in (("weights", self.net.weights[k]), ("biases", self.net.biases[k])):
-                    key = "conv%d/%s/Momentum" % (k + 1, name)
-                    if key in z.files:
-                        a = z[key]
-                        a = np.transpose(a, (3, 2, 0, 1)) if a.ndim == 4 else a
-                        self.opt.state[p]["momentum_buffer"] = torch.from_numpy(np.ascontiguousarray(a)).to(p.device)
+            slots = {k: z[k] for k in z.files if k.endswith("/Momentum")}
+        else:
+            slots = {k: v for k, v in tf_checkpoint.load_checkpoint(path, skip_slots=False).items()
+                     if k.endswith("/Momentum")}
+        for k in range(self.net.num_conv_layers):
+            for name, p in (("weights", self.net.weights[k]), ("biases", self.net.biases[k])):
+                a = slots.get("conv%d/%s/Momentum" % (k + 1, name))
+                if a is not None:
+                    a = np.transpose(a, (3, 2, 0, 1)) if a.ndim == 4 else a
+                    self.opt.state[p]["momentum_buffer"] = torch.from_numpy(np.ascontiguousarray(a)).to(p.device)
 
 
 def main(argv=None):
@@ -125,9 +136,12 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1:
-        os.environ["HIP_VISIBLE_DEVICES"] = args.gpu
-        os.environ["CUDA_VISIBLE_DEVICES"] = args.gpu
+    import sys
+    words = sys.argv[1:] if argv is None else list(argv)
+    explicit = any(w in ("-g", "--gpu") or w.startswith("--gpu=") for w in words)
+    if world == 1 and (explicit or "HIP_VISIBLE_DEVICES" not in os.environ):
+        os.environ["HIP_VISIBLE_DEVICES"] = args.gpu   # an explicit -g pins the card (train.py:57); otherwise a
+        os.environ["CUDA_VISIBLE_DEVICES"] = args.gpu  # scheduler's HIP_VISIBLE_DEVICES stands
 
     import torch
     import distributed as mgpu

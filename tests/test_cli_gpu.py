@@ -164,3 +164,64 @@ def test_training_step_on_the_gpu_and_weights_feed_the_matcher(net_layers):
     import torch
     out = m.match(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda(), D)
     assert out.shape == (H, W) and bool(torch.isfinite(out).all())
+
+
+def test_training_step_matches_float64_evaluation_of_the_reference_graph():
+    """(f3) pinned the way a1 is: TWO Trainer.step calls on cuda:0 (MIOpen forward / backward / weight gradients)
+    against a float64 evaluation, on the CPU, of what /root/reference/src/train.py:71-106 builds - three weight-shared
+    towers of five VALID 3x3 convolutions with ReLU (model.py:51-61), tf.nn.l2_normalize (model.py:64), cosine of the
+    unit vectors (train.py:85-87), hinge with margin (train.py:90-93), tf.train.MomentumOptimizer (accum = beta * accum
+    + grad; var -= lr * accum, train.py:105-106).  The arithmetic itself lives in TensorFlow (parity unpinned at that
+    boundary, like the feature stage); tolerance 1e-5 on both losses and on all ten updated tensors."""
+    import torch
+    import torch.nn.functional as F
+    import train
+    from model import NET
+    rng = np.random.default_rng(5)
+    B, lr, beta, margin = 64, 0.02, 0.9, 0.2
+    base = rng.standard_normal((B, 11, 11, 1)).astype(np.float32)
+    batches = []
+    for _ in range(2):
+        batches.append([base + 0.1 * rng.standard_normal(base.shape).astype(np.float32),
+                        base + 0.1 * rng.standard_normal(base.shape).astype(np.float32),
+                        rng.standard_normal(base.shape).astype(np.float32)])
+    net = NET(None, batch_size=B, device="cuda", seed=7)
+    start = net.get_layers()                                   # HWIO weights + biases, float32
+    t = train.Trainer(net, lr, beta, margin)
+    gpu_losses = [t.step(*b) for b in batches]
+    got = net.get_layers()
+
+    # float64 evaluation with its own statement of the graph (no code shared with model.NET / train.hinge_loss)
+    ws = [torch.tensor(np.transpose(w, (3, 2, 0, 1)).astype(np.float64), requires_grad=True) for w, _ in start]
+    bs = [torch.tensor(b.astype(np.float64), requires_grad=True) for _, b in start]
+    acc = [torch.zeros_like(p) for p in ws + bs]
+    ref_losses = []
+    for batch in batches:
+        feats = []
+        for patches in batch:                                  # the three towers share ws / bs
+            x = torch.tensor(patches.astype(np.float64)).permute(0, 3, 1, 2)
+            for k in range(5):
+                x = F.conv2d(x, ws[k], bs[k])
+                if k < 4:
+                    x = torch.relu(x)
+            x = x.reshape(B, 64)
+            feats.append(x * torch.rsqrt(torch.clamp((x * x).sum(dim=1, keepdim=True), min=1e-12)))
+        pos = (feats[0] * feats[1]).sum(dim=1)
+        neg = (feats[0] * feats[2]).sum(dim=1)
+        loss = torch.clamp(margin - pos + neg, min=0.0).mean()
+        ref_losses.append(float(loss.detach()))
+        grads = torch.autograd.grad(loss, ws + bs)
+        with torch.no_grad():
+            for p, a, g in zip(ws + bs, acc, grads):
+                a.mul_(beta).add_(g)
+                p.sub_(lr * a)
+    assert ref_losses[0] > 0.01, "degenerate test batch: the hinge is inactive"
+    for a, b in zip(gpu_losses, ref_losses):
+        assert abs(a - b) <= 1e-5, (gpu_losses, ref_losses)
+    worst = 0.0
+    for k, (w, b) in enumerate(got):
+        worst = max(worst, float(np.abs(np.transpose(w, (3, 2, 0, 1)) - ws[k].detach().numpy()).max()),
+                    float(np.abs(b - bs[k].detach().numpy()).max()))
+    moved = max(float(np.abs(got[k][0] - start[k][0]).max()) for k in range(5))
+    assert moved > 1e-4, "the step did not move the weights"
+    assert worst <= 1e-5, "updated tensors differ from the float64 evaluation by %g" % worst

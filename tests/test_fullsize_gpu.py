@@ -3,7 +3,7 @@
 cfg1 (256x256, D=64) is small enough for the CPU checker to follow a WHOLE pair stage by stage (each stage of the GPU
 run is fed, on the CPU, the GPU's own output of the stage before - identical inputs, so the bit-exact variants must be
 bit-identical and the fast variants stay within their stated per-stage tolerance).  The measured differences are written
-to gpurun_out/parity_r02.json (copied to profiles/ by hand) so that the numbers behind the bounds are on record.
+to gpurun_out/parity_r03.json (copied to profiles/ by hand) so that the numbers behind the bounds are on record.
 cfg3 (1242x375, D=192) gets the size-independent properties and an oracle window at its full width.
 """
 import json
@@ -29,7 +29,7 @@ def _dump():
     out_dir = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(out_dir, exist_ok=True)
-        with open(os.path.join(out_dir, "parity_r02.json"), "w") as f:
+        with open(os.path.join(out_dir, "parity_r03.json"), "w") as f:
             json.dump(RECORD, f, indent=1, sort_keys=True)
     except OSError:
         pass
@@ -138,6 +138,55 @@ def test_cfg1_whole_pair_stage_by_stage(net_layers):
     assert d["wta_mismatches"] == 0
     assert flips <= fast_map.size // 500, "fast variants flip %d WTA decisions of %d" % (flips, fast_map.size)
     assert close >= 0.985, "only %.4f of the pixels within 1e-3 px of the bit-exact run" % close
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3"])
+def test_benchmarked_path_against_bit_exact_variant_full_size(net_layers, cfg):
+    """What bench.py times - fast variants + split-operand features, replayed as one hipGraph - at BASELINE's full
+    sizes: (1) the replay is bit-identical to the same matcher launched kernel by kernel; (2) against the bit-exact
+    variant (oracle-pinned stage by stage at cfg1 and on ragged shapes, hence the full-size proxy for the reference):
+    index-exact WTA up to a handful of near-ties, final map within the fast variant's stated tolerance; (3) the
+    bit-exact variant on pixel-major volumes equals its plane-major twin bit for bit."""
+    import _hipabi as hip
+    import stereo_device as sd
+    import synthetic
+    from bench import CONFIGS
+    from model import NET
+    H, W, D = CONFIGS[cfg]
+    L, R, _, _, _ = synthetic.make_pair(H, W, D, seed=100)
+    l, r = dev(L[:, :, 0]), dev(R[:, :, 0])
+    net = NET(None, input_patch_size=11, batch_size=1, device="cuda").set_layers(net_layers)
+    fast = sd.StereoMatcher(net, cv_mode=hip.MCCNN_CV_MFMA, cbca_order=hip.MCCNN_CBCA_SEPARABLE, features="split_f16")
+    replay = fast.match_graph(l, r, D).clone()
+    kf = {}
+    eager = fast.match(l, r, D, keep=kf)
+    assert torch.equal(replay.view(torch.int32), eager.view(torch.int32)), "graph replay differs from the eager launch"
+    exact = sd.StereoMatcher(net, cv_mode=hip.MCCNN_CV_EXACT, cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER)
+    ke = {}
+    emap = exact.match(l, r, D, keep=ke)
+    twin = sd.StereoMatcher(net, cv_mode=hip.MCCNN_CV_EXACT, cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER,
+                            layout="plane_major")
+    kt = {}
+    tmap = twin.match(l, r, D, keep=kt)
+    for k in ("cbca1", "sgm", "cbca2"):
+        assert torch.equal(ke[k][0], kt[k][0]) and torch.equal(ke[k][1], kt[k][1]), "pixel-major %s differs" % k
+    assert torch.equal(emap.view(torch.int32), tmap.view(torch.int32))
+    a, b = eager.cpu().numpy(), emap.cpu().numpy()
+    flips = int((kf["wta"][0] != ke["wta"][0]).sum()) + int((kf["wta"][1] != ke["wta"][1]).sum())
+    close = float(np.isclose(a, b, atol=1e-3, equal_nan=True).mean())
+    fin = np.isfinite(a) & np.isfinite(b)
+    RECORD[cfg + "_benchmarked_fast_variant_vs_exact"] = {
+        "pixels": int(a.size), "wta_flips_left_plus_right": flips, "fraction_within_1e-3_px": close,
+        "max_abs_px": float(np.abs(a[fin] - b[fin]).max()),
+        "abs_px_99.9th_percentile": float(np.percentile(np.abs(a[fin] - b[fin]), 99.9)), "graph_replay_equals_eager": True,
+        "exact_pixel_major_equals_plane_major": True}
+    _dump()
+    # measured: 0 flips at cfg2, 2 of 931 500 at cfg3 (a flipped near-tie moves its pixel by many disparities, so the
+    # largest difference is not bounded; the 99.9th percentile is); 98.7-99.5 % within 1e-3 px (the sub-pixel parabola
+    # amplifies 1e-7-level differences of the features, so this fraction moves with MIOpen's choice of algorithm)
+    assert flips <= a.size // 10000, "%s: %d WTA flips" % (cfg, flips)
+    assert close >= 0.98, "%s: only %.4f within 1e-3 px" % (cfg, close)
+    assert float(np.percentile(np.abs(a[fin] - b[fin]), 99.9)) <= 0.1
 
 
 def test_cfg3_full_size_properties():

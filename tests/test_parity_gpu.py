@@ -165,6 +165,12 @@ def test_golden_features(pf, golden_cases, net_layers):
         assert fl.shape == g["fl"].shape and fl.dtype == np.float32
         assert np.abs(fl - g["fl"]).max() <= 1e-5, name   # vs the float64-accumulating restatement
         assert np.abs(fr - g["fr"]).max() <= 1e-5, name
+        # (f2) the row-banded evaluation straight against the same golden features (bands of 7 and 16 rows: several
+        # bands with overlapped halos on the 24- and 40-row golden images)
+        for rows in (7, 16):
+            tl, tr = net.features_pair_hwc(dev(g["left"][:, :, 0]), dev(g["right"][:, :, 0]), tile_rows=rows)
+            assert np.abs(tl.cpu().numpy() - g["fl"]).max() <= 1e-5, (name, rows)
+            assert np.abs(tr.cpu().numpy() - g["fr"]).max() <= 1e-5, (name, rows)
 
 
 def test_golden_whole_pair_reference_order(sd, golden_cases, net_layers):
@@ -648,13 +654,15 @@ def test_graph_replay_equals_kernel_by_kernel(sd, net_layers):
     from model import NET
     H, W, D = 64, 96, 24
     net = NET(None, input_patch_size=11, batch_size=1, device="cuda").set_layers(net_layers)
-    for cv, order in ((hip.MCCNN_CV_MFMA, hip.MCCNN_CBCA_SEPARABLE), (hip.MCCNN_CV_EXACT, hip.MCCNN_CBCA_REFERENCE_ORDER)):
-        m = sd.StereoMatcher(net, cv_mode=cv, cbca_order=order)
+    for cv, order, feat in ((hip.MCCNN_CV_MFMA, hip.MCCNN_CBCA_SEPARABLE, "miopen"),
+                            (hip.MCCNN_CV_MFMA, hip.MCCNN_CBCA_SEPARABLE, "split_f16"),      # what bench.py / --fast time
+                            (hip.MCCNN_CV_EXACT, hip.MCCNN_CBCA_REFERENCE_ORDER, "miopen")):  # pixel-major pipeline
+        m = sd.StereoMatcher(net, cv_mode=cv, cbca_order=order, features=feat)
         for seed in (1, 2, 3):
             L, R, _, _, _ = synthetic.make_pair(H, W, D, seed=seed)
             l, r = dev(L[:, :, 0]), dev(R[:, :, 0])
             want = m.match(l, r, D).clone()
             got = m.match_graph(l, r, D)
             torch.cuda.synchronize()
-            assert np.array_equal(got.cpu().numpy(), want.cpu().numpy(), equal_nan=True), (cv, order, seed)
+            assert np.array_equal(got.cpu().numpy(), want.cpu().numpy(), equal_nan=True), (cv, order, feat, seed)
         assert len(m._graphs) == 1
