@@ -606,15 +606,23 @@ extern "C" int mccnn_sgm_pass(const float *image_left, const float *image_right,
     const dim3 grid(nlines, n_jobs), block(64);
     MCCNN_REQUIRE((size_t)H * W * P.Dp * 4 < ((size_t)1 << 32), MCCNN_E_UNSUPPORTED,
                   "mccnn_sgm_pass: %dx%dx%d volume exceeds the 4 GiB reach of a buffer descriptor", W, H, D);
-    // steps in flight: 8, 12 and 16 measure the same on a warm chip (0.30 / 0.29 ms per pass at 750x500x256)
+    // steps in flight: 8, 12 and 16 measure the same at 750x500x256 (0.30 / 0.29 ms per pass: 1000-1500 scanline waves);
+    // a 1242x375 pair has only 750 row scanlines - fewer waves than SIMDs - and its horizontal passes gain from 24 steps
+    // (0.388 -> 0.342 ms); two disparity groups per lane (D > 256) take 12 (vertical 2.17 -> 2.06 ms at 1500x1000x400)
+#ifndef SGM_PF_PARTIAL
+#define SGM_PF_PARTIAL 24
+#endif
+#ifndef SGM_PF_2G
+#define SGM_PF_2G 12
+#endif
     if (D == 256)
         hipLaunchKernelGGL((sgm_pass_kernel<1, 16, true>), grid, block, 0, s, P);
     else if (D < 256)
-        hipLaunchKernelGGL((sgm_pass_kernel<1, 8, false>), grid, block, 0, s, P);
+        hipLaunchKernelGGL((sgm_pass_kernel<1, SGM_PF_PARTIAL, false>), grid, block, 0, s, P);
     else if (D == 512)
-        hipLaunchKernelGGL((sgm_pass_kernel<2, 4, true>), grid, block, 0, s, P);
+        hipLaunchKernelGGL((sgm_pass_kernel<2, SGM_PF_2G, true>), grid, block, 0, s, P);
     else
-        hipLaunchKernelGGL((sgm_pass_kernel<2, 4, false>), grid, block, 0, s, P);
+        hipLaunchKernelGGL((sgm_pass_kernel<2, SGM_PF_2G, false>), grid, block, 0, s, P);
     return check_launch("mccnn_sgm_pass");
 }
 
