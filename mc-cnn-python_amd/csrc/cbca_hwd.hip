@@ -194,21 +194,50 @@ struct Jobs {
     int n;
 };
 
-// grid = (8 * nyb, ngroups, nchunks * jobs): blockIdx.x & 7 = XCD = band of `band_rows` image rows (a multiple of 4),
-// blockIdx.x >> 3 = group of 4 rows inside the band (one row per wave), blockIdx.y = group of G columns,
-// blockIdx.z = (job, chunk of 64 * VPL disparities).  Dispatch order is x fastest, then y: inside its band an XCD
-// sweeps column group by column group.
+// A wave owns a patch of K x G anchors: rows y0 .. y0 + K - 1 (y0 a multiple of K), columns x0 .. x0 + G - 1.
+// Vertically adjacent anchors walk almost the same rows, but each in its own order (self, up 1.., down 1..), so the
+// rows are visited in ONE descending sweep y0 + K - 1 ... lowest row any anchor reaches - anchor k joins at its own
+// row y0 + k (its "self") and stays until its upper arm ends - and then ONE ascending sweep y0 + 1 ... highest row -
+// anchor k joins at y0 + k + 1, after its upper arm is complete, and stays until its lower arm ends.  Every anchor
+// still sees self, up 1.., down 1.. (pf:155), and a row's window is loaded once for the K anchors instead of K times:
+// in long-arm zones, where the vector memory pipe (64 B/clk/CU) is what bounds this kernel, that is ~K times fewer
+// bytes per output.  The K anchors of a column meet the same row pixel, i.e. the same window mask; bit t of
+// sched[k][j] says whether anchor (k, j) takes part in step t of the two sweeps.
+//
+// grid = (8 * nyb, ngroups, nchunks * jobs): blockIdx.x & 7 = XCD = band of `band_rows` image rows (a multiple of
+// K * WPB), blockIdx.x >> 3 = group of K * WPB rows inside the band (K rows per wave), blockIdx.y = group of G
+// columns, blockIdx.z = (job, chunk of 64 * VPL disparities).  Dispatch order is x fastest, then y: inside its band
+// an XCD sweeps column group by column group.
 #ifndef CBCA_HWD_MINW
 #define CBCA_HWD_MINW 1
 #endif
+#ifndef CBCA_HWD_K
+#define CBCA_HWD_K 2
+#endif
+constexpr int K = CBCA_HWD_K;
+static_assert(2 * K + 2 * R - 1 <= 32, "the sweep schedule is a 32-bit word");
+
+template <int VPL, int KK>
+__device__ __forceinline__ void walk_anchor_rows(typename Vec<VPL>::T (&acc)[K][G], const typename Vec<VPL>::T (&win)[NW],
+                                                 const wm_t (&roww)[G], const uint32_t (&sched)[K][G], int t)
+{
+    if constexpr (KK < K) {
+        wm_t m[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) m[j] = (sched[KK][j] >> t) & 1u ? roww[j] : (wm_t)0;
+        walk_rows<VPL, 0>(acc[KK], win, m);
+        walk_anchor_rows<VPL, KK + 1>(acc, win, roww, sched, t);
+    }
+}
+
 template <int VPL>
 __global__ __launch_bounds__(64 * CBCA_HWD_WPB, CBCA_HWD_MINW) void cbca_hwd_kernel(const Jobs jobs, int Dp, int H, int W, int nchunks, int band_rows)
 {
     typedef typename Vec<VPL>::T vf;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int y = (int)(blockIdx.x & 7) * band_rows + (int)(blockIdx.x >> 3) * CBCA_HWD_WPB + wv;
-    if (y >= H) return;
+    const int y0 = (int)(blockIdx.x & 7) * band_rows + ((int)(blockIdx.x >> 3) * CBCA_HWD_WPB + wv) * K;
+    if (y0 >= H) return;
     const int x0 = (int)blockIdx.y * G;
     const int job = (int)blockIdx.z / nchunks, chunk = (int)blockIdx.z - job * nchunks;
     const float *const in = job ? jobs.in[1] : jobs.in[0];
@@ -218,73 +247,94 @@ __global__ __launch_bounds__(64 * CBCA_HWD_WPB, CBCA_HWD_MINW) void cbca_hwd_ker
         reinterpret_cast<const wm_t *>(reinterpret_cast<const char *>(sup) + wmask_plane_offset(H, W));
 
     const unsigned pix = (unsigned)Dp * 4u;                       // bytes between neighbouring pixels
-    const int row0 = max(y - R, 0), row1 = min(y + R, H - 1);      // rows any arm of this group can reach
+    const int ytop = min(y0 + K - 1, H - 1);                       // last anchor row inside the image
+    const int row0 = max(y0 - R, 0), row1 = min(ytop + R, H - 1);  // rows any arm of this patch can reach
     const size_t rowf = (size_t)W * Dp;                            // floats per image row
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(in + (size_t)row0 * rowf), 0, (int)((size_t)(row1 - row0 + 1) * rowf * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-        out + ((size_t)y * W + x0) * Dp, 0, (int)((unsigned)min(G, W - x0) * pix), 0x00020000);
     const int d0 = (chunk * 64 + lane) * VPL;
     const int voff = d0 < Dp ? d0 * 4 : kDrop;                     // lanes past the disparity range: loads 0, stores dropped
 
-    // anchors: vertical arms and region sizes (plane 0), window masks of the anchor row.  The words of a group that
-    // straddles the right edge are read (they lie inside the support buffer) but never used: their schedule is empty.
-    const size_t p0 = (size_t)y * W + x0;
-    uint32_t aw[G];
-    wm_t nxt[G];
+    // anchors: vertical arms (plane 0) -> the sweep schedule.  The words of a patch that straddles the right or the
+    // bottom edge are read from clamped rows / inside the support buffer and never used: their schedule is empty.
+    uint32_t sched[K][G];
+    int lowest = y0, highest = y0;
 #pragma unroll
-    for (int j = 0; j < G; ++j) {
-        aw[j] = sup[p0 + j];
-        nxt[j] = wmask[p0 + j];
-    }
-    int up[G], dn[G], umax = 0, dmax = 0;
-#pragma unroll
-    for (int j = 0; j < G; ++j) {
-        const bool ok = x0 + j < W;
-        up[j] = ok ? min(arm_up(aw[j]), y) : -1;                  // clamped to the image: the scalar loads below stay
-        dn[j] = ok ? min(arm_down(aw[j]), H - 1 - y) : 0;         // inside the plane whatever the words say
-        umax = max(umax, up[j]);
-        dmax = max(dmax, dn[j]);
-    }
-    // step t of the walk visits row y (t = 0), y - t (t <= umax), y + (t - umax) (pf:155 list order: self, up, down);
-    // bit t of sched[j] says whether pixel j's vertical arm includes that row
-    uint32_t sched[G];
-#pragma unroll
-    for (int j = 0; j < G; ++j)
-        sched[j] = up[j] < 0 ? 0u : (((2u << up[j]) - 1u) | (((1u << dn[j]) - 1u) << (umax + 1)));
-    const int nrows = 1 + umax + dmax;
-
-    vf acc[G];
-#pragma unroll
-    for (int j = 0; j < G; ++j) acc[j] = Vec<VPL>::zero();         // pf:156 sum starts at 0
-
-    int yq = y;
-    for (int t = 0; t < nrows; ++t) {
-        wm_t m[G], u = 0;
+    for (int k = 0; k < K; ++k) {
+        const int y = y0 + k;
+        const size_t p0 = (size_t)min(y, H - 1) * W + x0;
 #pragma unroll
         for (int j = 0; j < G; ++j) {
-            m[j] = (sched[j] >> t) & 1u ? nxt[j] : (wm_t)0;
-            u |= m[j];
+            const uint32_t aw = sup[p0 + j];
+            const bool ok = x0 + j < W && y < H;
+            const int up = min(arm_up(aw), y), dn = min(arm_down(aw), H - 1 - y);   // clamped to the image: the scalar
+            if (ok) {                                                                // loads below stay inside the plane
+                lowest = min(lowest, y - up);
+                highest = max(highest, dn > 0 ? y + dn : y0);
+            }
+            // descending step s visits row y0 + K - 1 - s: anchor k takes part for s in [K-1-k, K-1-k+up];
+            // ascending step a visits row y0 + 1 + a: for a in [k, k+dn-1].  The ascending bits are placed once the
+            // number of descending steps is known (below).
+            sched[k][j] = ok ? (((2u << up) - 1u) << (K - 1 - k)) | ((((1u << dn) - 1u) << k) << 16) : 0u;
         }
+    }
+    const int nd = y0 + K - 1 - lowest + 1;                        // descending steps: rows y0+K-1 .. lowest
+    const int na = highest - y0;                                   // ascending steps: rows y0+1 .. highest
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int j = 0; j < G; ++j) sched[k][j] = (sched[k][j] & 0xFFFFu) | ((sched[k][j] >> 16) << nd);
+    const int nsteps = nd + na;
+    auto row_of = [&](int t) { return t < nd ? y0 + K - 1 - t : y0 + 1 + (t - nd); };
+
+    vf acc[K][G];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int j = 0; j < G; ++j) acc[k][j] = Vec<VPL>::zero();  // pf:156 sum starts at 0
+
+    wm_t nxt[G];
+    {
+        const size_t pn = (size_t)min(row_of(0), H - 1) * W + x0;
+#pragma unroll
+        for (int j = 0; j < G; ++j) nxt[j] = wmask[pn + j];
+    }
+    for (int t = 0; t < nsteps; ++t) {
+        wm_t roww[G], u = 0;
+        uint32_t any[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            roww[j] = nxt[j];
+            any[j] = 0u;
+#pragma unroll
+            for (int k = 0; k < K; ++k) any[j] |= sched[k][j];
+            u |= (any[j] >> t) & 1u ? roww[j] : (wm_t)0;
+        }
+        const int yq = row_of(t);
         // slot k = column x0 - R + k; the offset may wrap below zero for slots left of the image, which no arm reaches
         const unsigned rowoff = (unsigned)(((yq - row0) * W + x0 - R) * (int)pix);
-        // the next row's masks travel while this row is loaded and summed (past the end: a harmless re-read)
-        const int tn = min(t + 1, nrows - 1);
-        yq = tn == 0 ? y : (tn <= umax ? y - tn : y + (tn - umax));
-        {
-            const size_t pn = (size_t)yq * W + x0;
+        {   // the next row's masks travel while this row is loaded and summed (past the end: a harmless re-read)
+            const size_t pn = (size_t)min(row_of(min(t + 1, nsteps - 1)), H - 1) * W + x0;
 #pragma unroll
             for (int j = 0; j < G; ++j) nxt[j] = wmask[pn + j];
         }
         vf win[NW];
         load_window<VPL, 0>(win, u, rs_in, voff, rowoff, pix);
-        walk_rows<VPL, 0>(acc, win, m);
+        walk_anchor_rows<VPL, 0>(acc, win, roww, sched, t);
     }
 #pragma unroll
-    for (int j = 0; j < G; ++j) {
-        if (up[j] >= 0) {
-            const float n = (float)sup_count(aw[j]);
-            const vf res = Vec<VPL>::div(acc[j], n);                             // pf:161
+    for (int k = 0; k < K; ++k) {
+        const int y = y0 + k;
+        if (y >= H) break;
+        // the descriptor ends with the row (or the patch): stores of columns past the right edge are dropped by its
+        // range check, so the loop needs no per-column validity (their counts are whatever word follows: never used)
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+            out + ((size_t)y * W + x0) * Dp, 0, (int)((unsigned)min(G, W - x0) * pix), 0x00020000);
+        const size_t p0 = (size_t)y * W + x0;
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const float n = (float)sup_count(sup[p0 + j]);
+            const vf res = Vec<VPL>::div(acc[k][j], n);            // pf:161
             Vec<VPL>::store(res, rs_out, voff, (unsigned)j * pix);
         }
     }
@@ -293,7 +343,7 @@ __global__ __launch_bounds__(64 * CBCA_HWD_WPB, CBCA_HWD_MINW) void cbca_hwd_ker
 static int launch(const Jobs &jobs, int D, int H, int W, hipStream_t s)
 {
     const int Dp = mccnn_hwd_pitch(D);
-    MCCNN_REQUIRE((size_t)(2 * R + 1) * W * Dp * 4 < ((size_t)1 << 31), MCCNN_E_UNSUPPORTED,
+    MCCNN_REQUIRE((size_t)(2 * R + K) * W * Dp * 4 < ((size_t)1 << 31), MCCNN_E_UNSUPPORTED,
                   "mccnn_cbca_iter_hwd: %d columns x %d disparities exceed a buffer descriptor's reach", W, D);
 #ifdef CBCA_HWD_VPL
     const int vpl = CBCA_HWD_VPL;
@@ -301,11 +351,11 @@ static int launch(const Jobs &jobs, int D, int H, int W, hipStream_t s)
     const int vpl = Dp > 128 ? 4 : 2;
 #endif
     const int nchunks = cdiv(Dp, 64 * vpl);
-    const int band_rows = cdiv(cdiv(H, 8), 4) * 4;
+    const int band_rows = cdiv(cdiv(H, 8), hw::K * CBCA_HWD_WPB) * hw::K * CBCA_HWD_WPB;
     const int ngroups = cdiv(W, G);
     MCCNN_REQUIRE(ngroups <= 65535 && nchunks * jobs.n <= 65535, MCCNN_E_UNSUPPORTED,
                   "mccnn_cbca_iter_hwd: %dx%dx%d exceeds the grid", W, H, D);
-    const dim3 grid(8 * (band_rows / CBCA_HWD_WPB), ngroups, nchunks * jobs.n), block(64 * CBCA_HWD_WPB);
+    const dim3 grid(8 * (band_rows / (hw::K * CBCA_HWD_WPB)), ngroups, nchunks * jobs.n), block(64 * CBCA_HWD_WPB);
     if (vpl == 4)
         hipLaunchKernelGGL(cbca_hwd_kernel<4>, grid, block, 0, s, jobs, Dp, H, W, nchunks, band_rows);
     else

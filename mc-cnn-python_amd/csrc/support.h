@@ -41,7 +41,7 @@ __host__ __device__ __forceinline__ size_t perm_plane_bytes(int H, int W)
 // so the union of a row's loads is an OR, "pixel sits this row out" is a zero mask, and every step of a chain is one
 // scalar bit test - the walk costs the scalar unit ~3 instructions per pixel and row instead of ~25.
 #ifndef CBCA_HWD_G
-#define CBCA_HWD_G 6
+#define CBCA_HWD_G 5
 #endif
 constexpr int HWD_G = CBCA_HWD_G;
 constexpr int HWD_R = 13;
