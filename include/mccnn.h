@@ -14,14 +14,23 @@
  *   - return 0 on success, otherwise a negative MCCNN_E_* code or the positive hipError_t of the failed launch;
  *     mccnn_last_error_string() describes the last failure on the calling thread
  *   - float32 everywhere (the reference's dtype); sizes are ints, byte offsets are 64-bit inside
+ *   - ONE piece of host-side state, the exception to "nothing is retained": mccnn_cross_arms / mccnn_cross_arms_pair
+ *     remember, per support-buffer ADDRESS, the (H, W, L) they built it for (a mutex-guarded process-global map of at
+ *     most 4096 entries, cleared when full).  The aggregation entry points consult it only to REFUSE a plane built for
+ *     another image size or with longer arms than the L they are told (MCCNN_E_INVALID); addresses it has never seen
+ *     pass.  It is keyed by address, not by allocation: a buffer that is freed and whose address is reused keeps its
+ *     stale entry until the next mccnn_cross_arms on that address - which every correct use performs before
+ *     aggregating with it.  No device memory is referenced by it.
  *
  * HBM layouts
  *   image     [H][W]        float32 (the reference's [H,W,1])
  *   features  [H][W][C]     float32, C = 64 (NET.features, NHWC)
- *   volume    "DHW" [D][H][W]   - the reference's layout; cost volume, CBCA, WTA, sub-pixel use it
- *             "HWD" [H][W][Dp]  - pixel-major, Dp = mccnn_hwd_pitch(D); the SGM scanline kernels use it
+ *   volume    "DHW" [D][H][W]   - the reference's layout; cost volume, the streaming CBCA and its WTA / sub-pixel
+ *             "HWD" [H][W][Dp]  - pixel-major, Dp = mccnn_hwd_pitch(D); the SGM scanline kernels, and the whole
+ *                                 bit-exact variant from the first aggregation on (mccnn_cbca_iter_hwd, mccnn_wta_hwd,
+ *                                 mccnn_subpixel_hwd)
  *   support   mccnn_support_bytes(H,W) bytes: plane 0 [H][W] uint32 words (four 5-bit cross-arm lengths + 12-bit
- *             region size, mccnn_support_t), then two derived planes private to the streaming aggregation kernel
+ *             region size, mccnn_support_t), then four derived planes private to the aggregation kernels
  *   maps      [H][W]        float32 disparity maps, int32 status / region counts
  */
 #ifndef MCCNN_H
@@ -67,14 +76,15 @@ int mccnn_cost_volume(const float *fl, const float *fr, int H, int W, int C, int
  *     bits 0-4 up | 5-9 down | 10-14 left | 15-19 right | 20-31 count        (arms <= 31, count <= 63*63)
  * hence L <= 32.  The reference's explicit coordinate list [H][W][(2L)^2][2] (padded with -1) is produced by
  * mccnn_cross_region_list for API compatibility only.
- * The support buffer holds three derived planes behind the first (each 16-byte aligned), private to the kernels
- * of mccnn_cbca_iter.  Two are written for the streaming kernel's LDS layout: [H][W] uint32 "hsum words" (LDS byte addresses of the two row-prefix
+ * The support buffer holds four derived planes behind the first (each 16-byte aligned), private to the kernels
+ * of mccnn_cbca_iter / mccnn_cbca_iter_hwd.  Two are written for the streaming kernel's LDS layout: [H][W] uint32 "hsum words" (LDS byte addresses of the two row-prefix
  * entries whose difference is the pixel's horizontal-arm sum) and [H][W] uint64 "emit words" (the float64 reciprocal
  * 1/count with the vertical arms in its 12 low mantissa bits; the 40 upper mantissa bits are chosen so that the word as
  * stored is the float64 nearest to 1/count).  The third lists, for every 16 x 64 pixel tile, its pixels in order of
- * falling region size (uint16 tile-local indices): the order in which the reference-order kernel deals pixels to lanes,
- * so that a wave's lanes walk regions of similar size.  Allocate mccnn_support_bytes(H, W) bytes (18 per pixel +
- * alignment);
+ * falling region size (uint16 tile-local indices): the order in which the plane-major reference-order kernel deals
+ * pixels to lanes, so that a wave's lanes walk regions of similar size.  The fourth, [H][W] uint32 "window masks", is
+ * what the pixel-major reference-order kernel (mccnn_cbca_iter_hwd) walks: one bit per column of its register window
+ * that the pixel's horizontal arm covers.  Allocate mccnn_support_bytes(H, W) bytes (22 per pixel + alignment);
  * mccnn_cross_arms fills all planes, and consumers that only want the arms / counts read the first H*W words. */
 typedef uint32_t mccnn_support_t; /* plane 0 layout [H][W] */
 size_t mccnn_support_bytes(int H, int W); /* whole buffer: all planes (0 for non-positive sizes) */

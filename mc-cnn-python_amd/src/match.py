@@ -18,6 +18,7 @@ Multi-GPU: launch one process per GPU with different -g / -s / -e, as the refere
 or use `torchrun --nproc-per-node N match.py ...`: rank r then takes the pairs i = r (mod N) of the window.
 """
 import argparse
+import contextlib
 import os
 import time
 from datetime import datetime
@@ -64,6 +65,12 @@ parser.add_argument("--fast", action="store_true",
                          "<= 2e-6; CBCA through float64 prefix sums, <= 1e-6 per iteration) - about 13x faster.  "
                          "Without it every stage after the conv features is bit-identical to the reference's NumPy code")
 parser.add_argument("--exact", action="store_true", help="(default; kept for compatibility) the bit-exact variants")
+parser.add_argument("--pairs_in_flight", type=int, default=1,
+                    help="stereo pairs matched concurrently on this GPU, each on its own HIP stream with its own "
+                         "workspace.  The kernels of a KITTI-sized or smaller pair do not fill 256 CUs (a 256x256x64 "
+                         "pair reaches a third of the throughput of a 750x500x256 one); 2 overlaps the launch ramps of "
+                         "one pair with the other.  Results are identical; timeMCCNN.txt then holds each pair's own "
+                         "wall time, overlap included")
 # opt-in departures from the reference's results: what the MC-CNN paper does and the reference names but leaves out
 parser.add_argument("--paper_support_regions", action="store_true",
                     help="CBCA support regions intersected with the other view's at every disparity (paper sec. 4.1; "
@@ -140,14 +147,28 @@ def main(argv=None):
     net = NET(None, input_patch_size=args.patch_size, num_conv_layers=(args.patch_size - 1) // 2, batch_size=1,
               device="cuda")
     net.restore(args.resume)  # loaded once and kept resident (the reference re-restores per pair)
-    matcher = sd.StereoMatcher(
+    in_flight = max(1, int(args.pairs_in_flight))
+    matchers = [sd.StereoMatcher(
         net, hyper_parameters(args),
         cv_mode=hip.MCCNN_CV_MFMA if args.fast else hip.MCCNN_CV_EXACT,
         cbca_order=hip.MCCNN_CBCA_SEPARABLE if args.fast else hip.MCCNN_CBCA_REFERENCE_ORDER,
         features="split_f16" if args.fast and args.patch_size >= 5 else "miopen",
         extras=dict(both_view_support=args.paper_support_regions,
                     interpolation_directions=16 if args.paper_interpolation else 4,
-                    occlusion_from_left=args.paper_interpolation, numpy1_promotion=args.numpy1_promotion))
+                    occlusion_from_left=args.paper_interpolation, numpy1_promotion=args.numpy1_promotion)) for _ in range(in_flight)]
+    streams = [torch.cuda.Stream() for _ in range(in_flight)] if in_flight > 1 else [None]
+    pending = []          # pairs launched and not yet written: (device map, done event, start time, output paths)
+    launched = 0
+
+    def finish(entry):
+        disparity, done, stTime, out_path, out_time_path, out_img_path = entry
+        done.synchronize()
+        left_disparity_map = disparity.cpu().numpy()
+        endTime = time.time()
+        util.saveDisparity(left_disparity_map, out_img_path)
+        util.writePfm(left_disparity_map, out_path)
+        util.saveTimeFile(endTime - stTime, out_time_path)
+        print("[{}] {}: {:.3f} s -> {}".format(rank, datetime.now(), endTime - stTime, out_path))
 
     for index in shard_indices(args.start, args.end, len(left_paths), rank, world):
         left_path = left_paths[index]
@@ -176,18 +197,25 @@ def main(argv=None):
         assert left_image.shape == (height, width, 1)
         assert right_image.shape == (height, width, 1)
 
-        # timed region (match.py:129-179): host arrays in, host array out, device-synchronised
+        # timed region (match.py:129-179): host arrays in, host array out, device-synchronised.  With several pairs
+        # in flight the pair is launched on its slot's stream and collected when the slot comes round again.
+        slot = launched % in_flight
+        launched += 1
+        if len(pending) == in_flight:
+            finish(pending.pop(0))        # the oldest pair is the one that used this slot
         stTime = time.time()
-        dev_l = torch.from_numpy(left_image).cuda()
-        dev_r = torch.from_numpy(right_image).cuda()
-        disparity = matcher.match(dev_l, dev_r, ndisp)
-        left_disparity_map = disparity.cpu().numpy()
-        endTime = time.time()
-
-        util.saveDisparity(left_disparity_map, out_img_path)
-        util.writePfm(left_disparity_map, out_path)
-        util.saveTimeFile(endTime - stTime, out_time_path)
-        print("[{}] {}: {:.3f} s -> {}".format(rank, datetime.now(), endTime - stTime, out_path))
+        ctx = torch.cuda.stream(streams[slot]) if in_flight > 1 else contextlib.nullcontext()
+        with ctx:
+            dev_l = torch.from_numpy(left_image).cuda()
+            dev_r = torch.from_numpy(right_image).cuda()
+            disparity = matchers[slot].match(dev_l, dev_r, ndisp)
+            done = torch.cuda.Event()
+            done.record()
+        pending.append((disparity, done, stTime, out_path, out_time_path, out_img_path))
+        if in_flight == 1:
+            finish(pending.pop(0))
+    while pending:
+        finish(pending.pop(0))
 
 
 if __name__ == "__main__":

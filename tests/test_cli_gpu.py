@@ -82,6 +82,25 @@ def test_bench_two_ranks_share_one_gpu():
     assert abs(d["value"] - want) <= 0.02 * want
 
 
+def test_bench_launches_itself_for_several_gpus():
+    """`python bench.py --gpus 2` started bare (no torchrun, no WORLD_SIZE): the script re-launches itself under
+    torch.distributed.run on 127.0.0.1 and rank 0 prints the one JSON line with both ranks' times - what a driver that
+    calls the N-GPU bench like the 1-GPU bench gets.  (Two ranks share the one GPU of the test box.)"""
+    import json
+    env = dict(os.environ, MCCNN_BENCH_SHARED_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config",
+           "cfg1", "--no-parity"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and len(d["per_rank_ms_per_step"]) == 2 and d["process_group"] == "gloo x2"
+    assert abs(max(d["per_rank_ms_per_step"]) - d["ms_per_step"]) <= 0.01 * d["ms_per_step"] + 1e-3
+
+
 def test_bench_world_size_one_through_rccl():
     """bench.py with the process group forced on at world size 1 (MCCNN_BENCH_FORCE_DIST=1): backend "nccl" = RCCL is
     initialised with a device id, and the barrier + all_gather of the multi-GPU path run on a device tensor - what an
@@ -225,3 +244,28 @@ def test_training_step_matches_float64_evaluation_of_the_reference_graph():
     moved = max(float(np.abs(got[k][0] - start[k][0]).max()) for k in range(5))
     assert moved > 1e-4, "the step did not move the weights"
     assert worst <= 1e-5, "updated tensors differ from the float64 evaluation by %g" % worst
+
+
+def test_match_cli_pairs_in_flight_writes_the_same_files(tmp_path):
+    """--pairs_in_flight 2 (two matchers, two streams, pairs of different shapes alternating between them) writes,
+    byte for byte, what the default one-pair-at-a-time run writes."""
+    data = tmp_path / "data"
+    shapes = [(32, 48, 8), (40, 64, 8), (32, 48, 8), (24, 40, 8), (40, 64, 8)]
+    rels = ["s/p%d" % i for i in range(len(shapes))]
+    for i, (rel, (H, W, D)) in enumerate(zip(rels, shapes)):
+        _write_pair(str(data / rel), H, W, D, seed=60 + i)
+    lst = tmp_path / "list.txt"
+    lst.write_text("".join("%s/im0.png\n" % (data / rel) for rel in rels))
+    script = os.path.join(ROOT, "mc-cnn-python_amd", "src", "match.py")
+    common = [sys.executable, script, "--list_file", str(lst), "--resume", os.path.join(GOLDEN_DIR, "mccnn_fast_weights.npz"),
+              "--data_dir", str(data), "-s", "0", "-e", "4", "-t", "r"]
+    for name, extra in (("one", []), ("two", ["--pairs_in_flight", "2"])):
+        r = subprocess.run(common + ["--save_dir", str(tmp_path / name)] + extra, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, timeout=900)
+        assert r.returncode == 0, r.stdout.decode()[-3000:]
+    for rel, (H, W, _) in zip(rels, shapes):
+        for root, fn in (("submit_r", "disp0MCCNN.pfm"), ("submit_r_imgs", "disp0MCCNN.pgm")):
+            a = (tmp_path / "one" / root / rel / fn).read_bytes()
+            b = (tmp_path / "two" / root / rel / fn).read_bytes()
+            assert a == b and len(a) > H * W, (rel, fn)
+        assert float((tmp_path / "two" / "submit_r" / rel / "timeMCCNN.txt").read_text()) > 0
