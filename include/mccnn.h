@@ -69,6 +69,12 @@ const char *mccnn_last_error_string(void);
 int mccnn_cost_volume(const float *fl, const float *fr, int H, int W, int C, int D, float *lcv, float *rcv, int mode,
                       mccnn_stream_t stream);
 
+/* The same volumes written pixel-major ("HWD" [H][W][Dp], the layout the bit-exact variant keeps from here to WTA),
+ * bit-identical to mccnn_cost_volume(MCCNN_CV_EXACT) followed by mccnn_dhw_to_hwd for d < D (the Dp - D pad entries of
+ * a pixel are not written).  MCCNN_CV_EXACT only; D <= 512. */
+int mccnn_cost_volume_hwd(const float *fl, const float *fr, int H, int W, int C, int D, float *lcv_hwd, float *rcv_hwd,
+                          int mode, mccnn_stream_t stream);
+
 /* ---- a3  compute_cross_region (pf:571-657) ----------------------------------------------------------------
  * Per pixel: the four arm lengths (<= L-1 per side, anchor-relative threshold |I(q)-I(p)| < tau) and the region
  * size count = sum over the vertical arm of (left+right+1), packed in one 32-bit word so that the aggregation

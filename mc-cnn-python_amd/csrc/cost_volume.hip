@@ -27,9 +27,15 @@ constexpr int CV_C = 64;    // feature channels (NET num_conv_feature_maps)
 #endif
 constexpr int CV_LD = 68;   // padded LDS row (floats): 16-B slot index = (row + c4) mod 16 -> conflict-free b128
 
+// PIXEL_MAJOR: the volumes are written "HWD" [H][W][Dp] (the layout the whole bit-exact variant works on) instead of
+// [D][H][W]: the 64 x 64 scores of the tile go through LDS (over the left-feature tile, which lives in registers by
+// then) - a left-volume pixel receives its 64 disparities as one 256-byte run, a right-volume pixel x = w - d receives
+// the anti-diagonal of the tile that belongs to it (up to 64 disparities, one dword per lane).  Entries with w < d
+// (left) and x >= W - d (right) are left to cost_volume_fill_hwd_kernel.
+template <bool PIXEL_MAJOR>
 __global__ __launch_bounds__(256) void cost_volume_exact_kernel(const float *__restrict__ fl,
                                                                 const float *__restrict__ fr, int H, int W, int D,
-                                                                float *__restrict__ lcv, float *__restrict__ rcv)
+                                                                float *__restrict__ lcv, float *__restrict__ rcv, int Dp)
 {
     __shared__ __attribute__((aligned(16))) float sR[(CV_TW + CV_DT - 1) * CV_LD];
     __shared__ __attribute__((aligned(16))) float sL[CV_TW * CV_LD];
@@ -62,6 +68,9 @@ __global__ __launch_bounds__(256) void cost_volume_exact_kernel(const float *__r
         a[c4 * 4 + 0] = v.x; a[c4 * 4 + 1] = v.y; a[c4 * 4 + 2] = v.z; a[c4 * 4 + 3] = v.w;
     }
     const size_t plane = (size_t)H * W;
+    constexpr int TP = 65;              // pitch of the score tile (PIXEL_MAJOR)
+    float *const sT = sL;               // every thread holds its left features in registers from here on
+    if (PIXEL_MAJOR) __syncthreads();
     for (int k = 0; k < 16; ++k) {
         const int d = d0 + dq * 16 + k;
         if (d >= D) break;
@@ -88,8 +97,28 @@ __global__ __launch_bounds__(256) void cost_volume_exact_kernel(const float *__r
             float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
             s = 0.f + s;  // np.sum adds the pairwise result to the identity
             s = -1.f * s;
-            lcv[(size_t)d * plane + rowbase + w] = s;
-            rcv[(size_t)d * plane + rowbase + (w - d)] = s;
+            if (PIXEL_MAJOR) {
+                sT[wl * TP + dq * 16 + k] = s;
+            } else {
+                lcv[(size_t)d * plane + rowbase + w] = s;
+                rcv[(size_t)d * plane + rowbase + (w - d)] = s;
+            }
+        }
+    }
+    if (PIXEL_MAJOR) {
+        __syncthreads();
+        const int nd = min(CV_DT, D - d0);           // disparities of this tile that exist
+        // left volume: pixel w0 + px, disparities d0 .. d0 + nd - 1 (those with d <= w), 64 lanes = 64 disparities
+        const int dl = tid & 63;
+        for (int px = tid >> 6; px < CV_TW; px += 4) {
+            const int ww = w0 + px, d = d0 + dl;
+            if (ww < W && dl < nd && ww >= d) lcv[(rowbase + ww) * (size_t)Dp + d] = sT[px * TP + dl];
+        }
+        // right volume: pixel x = w - d; its entries of this tile are (w = x + d, d), d0 <= d < d0 + nd
+        for (int xi = tid >> 6; xi < CV_TW + CV_DT - 1; xi += 4) {
+            const int x = xr0 + xi, d = d0 + dl, px = x + d - w0;      // tile row of w = x + d
+            if (x >= 0 && dl < nd && px >= 0 && px < CV_TW && w0 + px < W)
+                rcv[(rowbase + x) * (size_t)Dp + d] = sT[px * TP + dl];
         }
     }
 }
@@ -325,6 +354,76 @@ __global__ __launch_bounds__(64) void cost_volume_fill_kernel(float *__restrict_
     }
 }
 
+// Border recurrences (pf:94-95, 105-106) on pixel-major volumes: disparities on lanes (4 per lane and 256-group), one
+// wave per image row and side, sweeping the columns the borders touch.  Left volume: columns D+1 down to 0; a lane's
+// component d takes the stored score while column >= d (those are its three seeds when the sweep reaches d+2, d+1, d)
+// and the 3-tap mean of its last three values below that - the same float32 operations in the same order as the
+// plane-major fill kernel (NumPy sums the slice in ascending column order: nearest column first here, oldest first on
+// the right-volume side).  Right volume: columns W-D-2 up to W-1, scores while column < W - d.
+typedef uint32_t cv_u32x4 __attribute__((ext_vector_type(4)));
+template <int NG>
+__global__ __launch_bounds__(64) void cost_volume_fill_hwd_kernel(float *__restrict__ lcv, float *__restrict__ rcv, int D,
+                                                                  int Dp, int H, int W)
+{
+    constexpr int PF = 8;
+    constexpr int kDrop = 0x7ffffff0;
+    const int lane = threadIdx.x, h = blockIdx.x;
+    const bool left = blockIdx.y == 0;
+    float *row = (left ? lcv : rcv) + (size_t)h * W * Dp;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(row, 0, (int)((size_t)W * Dp * 4), 0x00020000);
+    const unsigned pix = (unsigned)Dp * 4u;
+    const int c_first = left ? D + 1 : max(W - D - 2, 0), nsteps = left ? D + 2 : W - c_first;
+    auto col = [&](int t) { return left ? c_first - t : c_first + t; };
+    int dbase[NG], voff[NG];
+    float x1[NG][4], x2[NG][4], x3[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        dbase[g] = g * 256 + lane * 4;
+        voff[g] = dbase[g] < Dp ? dbase[g] * 4 : kDrop;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x1[g][i] = x2[g][i] = x3[g][i] = 0.f;
+    }
+    cv_u32x4 buf[PF][NG];
+    auto issue = [&](int slot, int t) {
+        const unsigned so = (unsigned)col(min(t, nsteps - 1)) * pix;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) buf[slot][g] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[g], so, 0);
+    };
+#pragma unroll
+    for (int k = 0; k < PF; ++k) issue(k, k);
+    for (int t0 = 0; t0 < nsteps; t0 += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int t = t0 + k;
+            if (t >= nsteps) continue;
+            const int c = col(t);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const cv_u32x4 u = buf[k][g];
+                const float v[4] = {__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)};
+                cv_u32x4 o;
+                bool any = false;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int d = dbase[g] + i;
+                    const bool stored = left ? c >= d : c < W - d;     // the score itself (d >= D: pad, never used)
+                    float s = 0.f + x1[g][i];
+                    s = s + x2[g][i];
+                    s = s + x3[g][i];
+                    const float val = stored ? v[i] : s / 3.f;
+                    any |= !stored && d < D;
+                    if (left) { x3[g][i] = x2[g][i]; x2[g][i] = x1[g][i]; x1[g][i] = val; }     // x1 = column c + 1 next
+                    else      { x1[g][i] = x2[g][i]; x2[g][i] = x3[g][i]; x3[g][i] = val; }     // x3 = column c - 1 next
+                    o[i] = __float_as_uint(val);
+                }
+                // components that still hold their score are written back unchanged
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs, any ? voff[g] : kDrop, (unsigned)c * pix, 0);
+            }
+            issue(k, t + PF);
+        }
+    }
+}
+
 }  // namespace mccnn
 
 extern "C" int mccnn_cost_volume(const float *fl, const float *fr, int H, int W, int C, int D, float *lcv, float *rcv,
@@ -341,7 +440,7 @@ extern "C" int mccnn_cost_volume(const float *fl, const float *fr, int H, int W,
     const dim3 block(256);
     if (mode == MCCNN_CV_EXACT) {
         const dim3 grid(cdiv(W, CV_TW), H, cdiv(D, CV_DT));
-        hipLaunchKernelGGL(cost_volume_exact_kernel, grid, block, 0, s, fl, fr, H, W, D, lcv, rcv);
+        hipLaunchKernelGGL(cost_volume_exact_kernel<false>, grid, block, 0, s, fl, fr, H, W, D, lcv, rcv, 0);
     } else if (mode == MCCNN_CV_MFMA) {
         const int nwt = cdiv(W, 64), nbands = cdiv(D + 63, 64) + 1;
         const long total = (long)nwt * nbands * H;
@@ -356,4 +455,35 @@ extern "C" int mccnn_cost_volume(const float *fl, const float *fr, int H, int W,
     if (D > 1)
         hipLaunchKernelGGL(cost_volume_fill_kernel, dim3(cdiv(H, 64), D - 1, 2), dim3(64), 0, s, lcv, rcv, D, H, W);
     return check_launch("mccnn_cost_volume(fill)");
+}
+
+extern "C" int mccnn_cost_volume_hwd(const float *fl, const float *fr, int H, int W, int C, int D, float *lcv_hwd,
+                                     float *rcv_hwd, int mode, mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(fl && fr && lcv_hwd && rcv_hwd, MCCNN_E_INVALID, "mccnn_cost_volume_hwd: null pointer");
+    MCCNN_REQUIRE(H > 0 && W > 0 && D > 0, MCCNN_E_INVALID, "mccnn_cost_volume_hwd: non-positive size");
+    MCCNN_REQUIRE(C == CV_C, MCCNN_E_UNSUPPORTED, "mccnn_cost_volume_hwd: C=%d, kernels are built for 64 channels", C);
+    MCCNN_REQUIRE(D <= W - 2, MCCNN_E_UNSUPPORTED,
+                  "mccnn_cost_volume_hwd: D=%d needs W >= D+2 (the reference's border recurrence pf:106 is degenerate "
+                  "beyond that), W=%d", D, W);
+    MCCNN_REQUIRE(mode == MCCNN_CV_EXACT, MCCNN_E_UNSUPPORTED,
+                  "mccnn_cost_volume_hwd: only MCCNN_CV_EXACT writes pixel-major volumes (mode %d: use "
+                  "mccnn_cost_volume + mccnn_dhw_to_hwd)", mode);
+    MCCNN_REQUIRE(D <= 512, MCCNN_E_UNSUPPORTED, "mccnn_cost_volume_hwd: D=%d > 512", D);
+    const int Dp = mccnn_hwd_pitch(D);
+    MCCNN_REQUIRE((size_t)W * Dp * 4 < ((size_t)1 << 31), MCCNN_E_UNSUPPORTED,
+                  "mccnn_cost_volume_hwd: a %d x %d row exceeds a buffer descriptor's reach", W, D);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(cdiv(W, CV_TW), H, cdiv(D, CV_DT));
+    hipLaunchKernelGGL(cost_volume_exact_kernel<true>, grid, dim3(256), 0, s, fl, fr, H, W, D, lcv_hwd, rcv_hwd, Dp);
+    int rc = check_launch("mccnn_cost_volume_hwd");
+    if (rc) return rc;
+    if (D > 1) {
+        if (Dp <= 256)
+            hipLaunchKernelGGL(cost_volume_fill_hwd_kernel<1>, dim3(H, 2), dim3(64), 0, s, lcv_hwd, rcv_hwd, D, Dp, H, W);
+        else
+            hipLaunchKernelGGL(cost_volume_fill_hwd_kernel<2>, dim3(H, 2), dim3(64), 0, s, lcv_hwd, rcv_hwd, D, Dp, H, W);
+    }
+    return check_launch("mccnn_cost_volume_hwd(fill)");
 }

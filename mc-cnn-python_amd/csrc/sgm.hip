@@ -545,7 +545,10 @@ extern "C" int mccnn_hwd_to_dhw(const float *hwd, float *dhw, int D, int H, int 
     const long N = (long)H * W;
     const int Dp = mccnn_hwd_pitch(D);
     if ((N & 3) == 0 && ((uintptr_t)dhw & 15) == 0 && ((uintptr_t)hwd & 15) == 0)   // in: [N][Dp], out: [D][N]
-        hipLaunchKernelGGL(transpose_f4_kernel<128>, dim3(cdiv(Dp, 64), cdiv(N, 128)), dim3(256), 0,
+#ifndef SGM_T_BACK
+#define SGM_T_BACK 128
+#endif
+        hipLaunchKernelGGL(transpose_f4_kernel<SGM_T_BACK>, dim3(cdiv(Dp, 64), cdiv(N, SGM_T_BACK)), dim3(256), 0,
                            (hipStream_t)stream, hwd, dhw, N, (long)Dp, (long)Dp, N, (long)D, N);   // 512-byte runs
     else
         hipLaunchKernelGGL(hwd_to_dhw_kernel, dim3(cdiv(N, 64), cdiv(D, 64)), dim3(256), 0, (hipStream_t)stream, hwd,

@@ -32,6 +32,7 @@ SIGNATURES = {
     "mccnn_version": (_i, []),
     "mccnn_last_error_string": (ctypes.c_char_p, []),
     "mccnn_cost_volume": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "mccnn_cost_volume_hwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "mccnn_support_bytes": (_sz, [_i, _i]),
     "mccnn_cross_arms": (_i, [_vp, _i, _i, _f, _i, _vp, _vp]),
     "mccnn_cross_arms_pair": (_i, [_vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp]),

@@ -140,6 +140,20 @@ def cost_volume(fl, fr, ndisp, mode=hip.MCCNN_CV_EXACT, out=None):
     return lcv, rcv
 
 
+def cost_volume_hwd(fl, fr, ndisp, out=None):
+    """cost_volume(mode=MCCNN_CV_EXACT) written straight into pixel-major volumes [H,W,Dp] (mccnn_cost_volume_hwd)."""
+    H, W, C = fl.shape
+    dp = hwd_pitch(ndisp)
+    if out is None:
+        lcv = torch.zeros((H, W, dp), dtype=torch.float32, device=fl.device)
+        rcv = torch.zeros((H, W, dp), dtype=torch.float32, device=fl.device)
+    else:
+        lcv, rcv = out
+    hip.check(hip.load().mccnn_cost_volume_hwd(hip.ptr(fl), hip.ptr(fr), H, W, C, int(ndisp), hip.ptr(lcv), hip.ptr(rcv),
+                                               hip.MCCNN_CV_EXACT, hip.stream()), "mccnn_cost_volume_hwd")
+    return lcv, rcv
+
+
 # ---- a3 ----------------------------------------------------------------------------------------------------------
 def support_buffer(H, W, device):
     """An empty support plane (see cross_arms): the [H,W] view of a mccnn_support_bytes(H, W) allocation."""
@@ -610,12 +624,17 @@ class StereoMatcher(object):
             fl, fr = self.net.features_pair_hwc(L, R, tile_rows=self.feature_tile_rows)
         timer.stop()
 
+        # the bit-exact variant writes its cost volume pixel-major right away (nothing converts layouts after that)
+        direct = self.pixel_major() and self.cv_mode == hip.MCCNN_CV_EXACT and D <= 512
         timer.start("cost_volume")
-        lcv, rcv = cost_volume(fl, fr, D, self.cv_mode, out=(as_dhw(b0), as_dhw(b1)))
+        if direct:
+            lh, rh = cost_volume_hwd(fl, fr, D, out=(as_hwd(b2), as_hwd(b3)))
+        else:
+            lcv, rcv = cost_volume(fl, fr, D, self.cv_mode, out=(as_dhw(b0), as_dhw(b1)))
         timer.stop()
         del fl, fr
         if keep is not None:
-            keep["cv"] = (lcv.clone(), rcv.clone())
+            keep["cv"] = (hwd_to_dhw(lh, D), hwd_to_dhw(rh, D)) if direct else (lcv.clone(), rcv.clone())
 
         if overlap:
             torch.cuda.current_stream().wait_stream(self._side)
@@ -628,9 +647,10 @@ class StereoMatcher(object):
         m = ws["maps"] if keep is None else torch.empty_like(ws["maps"])
         if self.pixel_major():
             # ---- bit-exact variant: pixel-major from here on ----
-            timer.start("cv_to_pixel_major")
-            lh, rh = dhw_to_hwd(lcv, as_hwd(b2)), dhw_to_hwd(rcv, as_hwd(b3))
-            timer.stop()
+            if not direct:
+                timer.start("cv_to_pixel_major")
+                lh, rh = dhw_to_hwd(lcv, as_hwd(b2)), dhw_to_hwd(rcv, as_hwd(b3))
+                timer.stop()
             (lh, lt), (rh, rt) = cbca_hwd_pair(lh, as_hwd(b0), sup_l, rh, as_hwd(b1), sup_r, D,
                                                hp["cbca_num_iterations1"], hp["cbca_distance"], timer)
             if keep is not None:

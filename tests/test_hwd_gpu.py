@@ -194,3 +194,42 @@ def test_full_size_pixel_major_equals_plane_major(sd, cfg):
     got, _ = sd.cbca_hwd(hv, torch.empty_like(hv), sup, D, 1, 14)
     assert torch.equal(sd.hwd_to_dhw(got, D), ref)
     assert torch.equal(sd.wta_hwd(got, D), sd.wta(ref))
+
+
+def test_golden_cost_volume_pixel_major(sd, golden_cases):
+    """pf:78-113 written straight into pixel-major volumes: the reference's own cost volumes, bit for bit."""
+    for name, g in golden_cases:
+        D = g["cv_l"].shape[0]
+        lh, rh = sd.cost_volume_hwd(dev(g["fl"]), dev(g["fr"]), D)
+        assert_bits(sd.hwd_to_dhw(lh, D).cpu().numpy(), g["cv_l"], name + " cv_l")
+        assert_bits(sd.hwd_to_dhw(rh, D).cpu().numpy(), g["cv_r"], name + " cv_r")
+
+
+@pytest.mark.parametrize("H,W,D", [(21, 70, 40), (40, 200, 64), (12, 300, 256), (5, 66, 64), (7, 130, 128), (3, 450, 400),
+                                   (9, 35, 33), (4, 64, 1), (6, 131, 2), (2, 700, 130)])
+def test_cost_volume_pixel_major_equals_plane_major(sd, H, W, D):
+    """Tile edges (W and D either side of multiples of 64), D = W - 2 (the longest border the reference defines),
+    D = 1 (no border), two 256-disparity groups in the border sweep, features that are not unit vectors: the same bits
+    as the plane-major NumPy-order kernel, which is pinned against the golden vectors and the oracle."""
+    import _hipabi as hip
+    g = torch.Generator(device="cuda").manual_seed(H * W + D)
+    fl = torch.randn((H, W, 64), device="cuda", generator=g)
+    fr = torch.randn((H, W, 64), device="cuda", generator=g)
+    l0, r0 = sd.cost_volume(fl, fr, D, hip.MCCNN_CV_EXACT)
+    lh, rh = sd.cost_volume_hwd(fl, fr, D)
+    assert torch.equal(sd.hwd_to_dhw(lh, D), l0), "left volume"
+    assert torch.equal(sd.hwd_to_dhw(rh, D), r0), "right volume"
+
+
+def test_cost_volume_pixel_major_abi_errors(sd):
+    import _hipabi as hip
+    lib = hip.load()
+    f = torch.zeros((4, 40, 64), device="cuda")
+    o = torch.zeros((4, 40, 8), device="cuda")
+    st = hip.stream()
+    assert lib.mccnn_cost_volume_hwd(hip.ptr(f), hip.ptr(f), 4, 40, 64, 8, hip.ptr(o), hip.ptr(o), hip.MCCNN_CV_MFMA, st) \
+        == hip.MCCNN_E_UNSUPPORTED
+    assert lib.mccnn_cost_volume_hwd(hip.ptr(f), hip.ptr(f), 4, 40, 64, 39, hip.ptr(o), hip.ptr(o), hip.MCCNN_CV_EXACT, st) \
+        == hip.MCCNN_E_UNSUPPORTED
+    assert lib.mccnn_cost_volume_hwd(None, hip.ptr(f), 4, 40, 64, 8, hip.ptr(o), hip.ptr(o), hip.MCCNN_CV_EXACT, st) \
+        == hip.MCCNN_E_INVALID
