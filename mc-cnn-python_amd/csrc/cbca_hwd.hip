@@ -50,6 +50,9 @@ constexpr wm_t kOne = 1;
 #ifndef CBCA_HWD_ABL
 #define CBCA_HWD_ABL 0                 // timing-only ablations (wrong results): 1 no adds, 2 no window loads, 3 neither
 #endif
+#ifndef CBCA_HWD_ONLY
+#define CBCA_HWD_ONLY 0
+#endif
 #ifndef CBCA_HWD_BLOCK4
 #define CBCA_HWD_BLOCK4 0
 #endif
@@ -70,7 +73,7 @@ template <> struct Vec<4> {
     {
         u32x4 u;
         u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
-        __builtin_amdgcn_raw_buffer_store_b128(u, rs, voff, soff, CBCA_HWD_NTS);
+        buffer_store_b128<CBCA_HWD_NTS>(u, rs, voff, soff);
     }
     static __device__ __forceinline__ T zero() { T v = {0.f, 0.f, 0.f, 0.f}; return v; }
     // a += w as four v_add_f32: this file is built with -fno-slp-vectorize (Makefile), because clang otherwise packs the
@@ -285,6 +288,16 @@ __global__ __launch_bounds__(64 * CBCA_HWD_WPB, CBCA_HWD_MINW) void cbca_hwd_ker
 #pragma unroll
         for (int j = 0; j < G; ++j) sched[k][j] = (sched[k][j] & 0xFFFFu) | ((sched[k][j] >> 16) << nd);
     const int nsteps = nd + na;
+#if CBCA_HWD_ONLY
+    {   // timing-only diagnostic: 1 = only the patches whose anchors all have four zero arms run, 2 = only the others
+        uint32_t arms = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int j = 0; j < G; ++j) arms |= sup[(size_t)min(y0 + k, H - 1) * W + x0 + j] & 0xFFFFFu;
+        if ((arms == 0) != (CBCA_HWD_ONLY == 1)) return;
+    }
+#endif
     auto row_of = [&](int t) { return t < nd ? y0 + K - 1 - t : y0 + 1 + (t - nd); };
 
     vf acc[K][G];
@@ -312,7 +325,11 @@ __global__ __launch_bounds__(64 * CBCA_HWD_WPB, CBCA_HWD_MINW) void cbca_hwd_ker
         }
         const int yq = row_of(t);
         // slot k = column x0 - R + k; the offset may wrap below zero for slots left of the image, which no arm reaches
+#if (CBCA_HWD_ABL & 4)
+        const unsigned rowoff = (unsigned)((((yq - row0) & 1) * W + (x0 % 60) + 16 - R) * (int)pix);   // timing only: every load hits a cache
+#else
         const unsigned rowoff = (unsigned)(((yq - row0) * W + x0 - R) * (int)pix);
+#endif
         {   // the next row's masks travel while this row is loaded and summed (past the end: a harmless re-read)
             const size_t pn = (size_t)min(row_of(min(t + 1, nsteps - 1)), H - 1) * W + x0;
 #pragma unroll
@@ -322,21 +339,36 @@ __global__ __launch_bounds__(64 * CBCA_HWD_WPB, CBCA_HWD_MINW) void cbca_hwd_ker
         load_window<VPL, 0>(win, u, rs_in, voff, rowoff, pix);
         walk_anchor_rows<VPL, 0>(acc, win, roww, sched, t);
     }
+    // Epilogue: every region size first (scalar loads: after the first store the compiler no longer trusts `sup` to be
+    // unchanged and turns each later read into a vector load + a full wait), then every quotient into registers of
+    // its own, then the stores back to back behind a scheduling barrier.  The barrier is load-bearing: with divisions
+    // and stores interleaved, the next column's division reuses the registers a buffer_store_dwordx4 is still
+    // reading (the compiler leaves the 2 wait states it knows about; on gfx950 the store then picked up the next
+    // division's intermediate in lanes 12-15 of every 16 - observed as wrong first components, tools/dev_hwd_where.py).
+    float cnt[K][G];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const size_t p0 = (size_t)min(y0 + k, H - 1) * W + x0;
+#pragma unroll
+        for (int j = 0; j < G; ++j) cnt[k][j] = (float)sup_count(sup[p0 + j]);
+    }
+    vf res[K][G];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int j = 0; j < G; ++j) res[k][j] = Vec<VPL>::div(acc[k][j], cnt[k][j]);   // pf:161
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int y = y0 + k;
-        if (y >= H) break;
         // the descriptor ends with the row (or the patch): stores of columns past the right edge are dropped by its
-        // range check, so the loop needs no per-column validity (their counts are whatever word follows: never used)
+        // range check, so the loop needs no per-column validity (their counts are whatever word follows: never used);
+        // a row below the image gets an empty descriptor instead of a branch (a branch here lets the compiler sink that
+        // row's divisions behind it, back between the stores)
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-            out + ((size_t)y * W + x0) * Dp, 0, (int)((unsigned)min(G, W - x0) * pix), 0x00020000);
-        const size_t p0 = (size_t)y * W + x0;
+            out + ((size_t)y * W + x0) * Dp, 0, y < H ? (int)((unsigned)min(G, W - x0) * pix) : 0, 0x00020000);
 #pragma unroll
-        for (int j = 0; j < G; ++j) {
-            const float n = (float)sup_count(sup[p0 + j]);
-            const vf res = Vec<VPL>::div(acc[k][j], n);            // pf:161
-            Vec<VPL>::store(res, rs_out, voff, (unsigned)j * pix);
-        }
+        for (int j = 0; j < G; ++j) Vec<VPL>::store(res[k][j], rs_out, voff, (unsigned)j * pix);
     }
 }
 

@@ -23,6 +23,21 @@ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // looked up per device (a process may drive several) and remembered.
 int device_cus8();
 
+// 16-byte buffer store + one wait state.  gfx950 hazard (tools/probe/storehazard.hip): when a VALU instruction writes
+// the store's first data register in the issue slot right behind a buffer_store_dwordx4 whose soffset is an SGPR, the
+// store picks up the NEW value in lanes 12-15 of every 16 (about 1 % of the stores under load).  The compiler pads
+// only the immediate-soffset form (2 wait states) and lets the register allocator reuse the data registers at once
+// otherwise; one wait state is enough, and data that came out of LDS or memory (not out of a VALU instruction right
+// in front of the store) is not affected.  The asm reads the data registers, so no later writer can move above it.
+#ifdef __HIPCC__
+template <int AUX, typename V4>
+__device__ __forceinline__ void buffer_store_b128(V4 v, __amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, soff, AUX);
+    asm volatile("s_nop 0" ::"v"(v));
+}
+#endif
+
 #define MCCNN_REQUIRE(cond, code, ...)        \
     do {                                      \
         if (!(cond)) {                        \

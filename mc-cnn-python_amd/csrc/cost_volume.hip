@@ -417,7 +417,7 @@ __global__ __launch_bounds__(64) void cost_volume_fill_hwd_kernel(float *__restr
                     o[i] = __float_as_uint(val);
                 }
                 // components that still hold their score are written back unchanged
-                __builtin_amdgcn_raw_buffer_store_b128(o, rs, any ? voff[g] : kDrop, (unsigned)c * pix, 0);
+                buffer_store_b128<0>(o, rs, any ? voff[g] : kDrop, (unsigned)c * pix);
             }
             issue(k, t + PF);
         }

@@ -821,7 +821,7 @@ __global__ __launch_bounds__(64 * PPW * (NSCAN + NHS + NEMIT)) void cbca_stream_
                     const double rn = __hiloint2double((int)hi, (int)lo);
                     o[j] = __float_as_uint((float)((qa[b][j] - qb[b][j]) * rn));
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(o, rs_dst, valid ? obf : kDrop, so, 0);
+                buffer_store_b128<0>(o, rs_dst, valid ? obf : kDrop, so);
                 if (ragged && valid && nval > 0 && nval < CPL) {   // the one lane that straddles the right edge
                     if (nval >= 2) {
                         u32x2 o2 = {o.x, o.y};

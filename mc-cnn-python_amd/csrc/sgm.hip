@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64) void sgm_pass_kernel(const SgmParams P)
                 sgm_u32x4 ou;
                 ou.x = __float_as_uint(o.x); ou.y = __float_as_uint(o.y);
                 ou.z = __float_as_uint(o.z); ou.w = __float_as_uint(o.w);
-                __builtin_amdgcn_raw_buffer_store_b128(ou, rs_vol, voff[g], pos(t) * vstride, kNT);
+                buffer_store_b128<kNT>(ou, rs_vol, voff[g], pos(t) * vstride);
                 lm = vmin(lm, vmin(vmin(o.x, o.y), vmin(o.z, o.w)));
             }
             issue(k, min(t + PF, nsteps));   // past the end: a harmless re-read of the last line (keeps the code branch-free)
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(64) void sgm_first_pass_kernel(const SgmFirstParams
             sgm_u32x4 ou;
             ou.x = __float_as_uint(o.x); ou.y = __float_as_uint(o.y);
             ou.z = __float_as_uint(o.z); ou.w = __float_as_uint(o.w);
-            __builtin_amdgcn_raw_buffer_store_b128(ou, rs_dst, voff, (unsigned)w * (unsigned)P.Dp * 4u, 0);
+            buffer_store_b128<0>(ou, rs_dst, voff, (unsigned)w * (unsigned)P.Dp * 4u);
             prev = o;
             m = wave_min(vmin(vmin(o.x, o.y), vmin(o.z, o.w)));
         }

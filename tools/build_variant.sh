@@ -8,7 +8,7 @@ NAME=$1; FLAGS=$2
 OUT=build/variants/$NAME; mkdir -p $OUT
 for f in csrc/*.hip; do
   o=$OUT/$(basename ${f%.hip}).o
-  X=""; [ "$(basename $f)" = cbca_hwd.hip ] && X="-fno-slp-vectorize"
+  X=""; [ "$(basename $f)" = cbca_hwd.hip ] && [ -z "$SLP" ] && X="-fno-slp-vectorize"
   /opt/rocm/bin/hipcc $X --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function $FLAGS -I../include -Icsrc -c $f -o $o 2>/dev/null &
 done
 wait
