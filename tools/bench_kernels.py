@@ -90,6 +90,13 @@ def main():
                                                       4.0, 8.0, 0.08, hip.ptr(scratch), scratch.numel(), hip.stream()),
                       "mccnn_sgm_first_pass")
         add("sgm_first_pass", first_pass, 4 * vol_bytes)
+    # the pixel-major kernels of the bit-exact variant (two-volume launches like the pair runs them)
+    if not only or only & {"cbca_iter_hwd", "cbca_iter_hwd_pair", "wta_hwd"}:
+        hb, hb2 = torch.empty_like(hwd), torch.empty_like(hwd2)
+        add("cbca_iter_hwd", lambda: sd.cbca_hwd(hwd, hb, sup, D, 1, 14), 2 * vol_bytes)
+        add("cbca_iter_hwd_pair", lambda: sd.cbca_hwd_pair(hwd, hb, sup, hwd2, hb2, sup2, D, 1, 14), 4 * vol_bytes)
+        add("wta_hwd", lambda: sd.wta_hwd(hwd, D), vol_bytes)
+        del hb, hb2
     add("dhw_to_hwd", lambda: sd.dhw_to_hwd(va, hwd), 2 * vol_bytes)
     add("hwd_to_dhw", lambda: sd.hwd_to_dhw(hwd, D, vb), 2 * vol_bytes)
     add("wta", lambda: sd.wta(va), vol_bytes)
