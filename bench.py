@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--exact", action="store_true",
                     help="bit-exact variants (NumPy-order cost volume, reference-order CBCA) instead of the fast ones")
+    ap.add_argument("--split-features", action="store_true",
+                    help="with --exact: the split-operand matrix-core conv features in front of the bit-exact stages "
+                         "(every stage after the features bit-identical to the reference given those features)")
     ap.add_argument("--library-features", action="store_true",
                     help="conv features through the float32 library convolutions (MIOpen) instead of the split-operand "
                          "matrix-core kernels")
@@ -179,10 +182,11 @@ def main():
     L, R, _, _, _ = synthetic.make_pair(H, W, D, seed=100 + rank)   # every rank owns a different pair
     dl = torch.from_numpy(L[:, :, 0]).cuda()
     dr = torch.from_numpy(R[:, :, 0]).cuda()
+    lib_features = args.library_features or (args.exact and not args.split_features)
     matcher = sd.StereoMatcher(
         net, cv_mode=hip.MCCNN_CV_EXACT if args.exact else hip.MCCNN_CV_MFMA,
         cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER if args.exact else hip.MCCNN_CBCA_SEPARABLE,
-        features="miopen" if (args.exact or args.library_features) else "split_f16")
+        features="miopen" if lib_features else "split_f16")
 
     use_graph = not args.no_graph
     if use_graph:
@@ -226,7 +230,7 @@ def main():
         out_timed = out.clone()
         keep_b = {}
         out_eager = matcher.match(dl, dr, D, keep=keep_b)
-        if args.exact:
+        if args.exact and lib_features:
             ref = sd.StereoMatcher(net, cv_mode=hip.MCCNN_CV_EXACT, cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER,
                                    features="miopen", layout="plane_major")
             ref_name = "bit-exact variant on plane-major volumes (round-2 reference-order kernels)"
@@ -252,7 +256,7 @@ def main():
             "final_map_bit_identical": bool(torch.equal(bits(out_eager), bits(out_ref))),
         }
         del keep_b, keep_e
-        if not args.exact:                        # the drop-in default, timed on the same box (5 pairs, graph replay)
+        if not (args.exact and lib_features):     # the drop-in default, timed on the same box (5 pairs, graph replay)
             try:
                 ref.match_graph(dl, dr, D)
                 go = lambda: ref.match_graph(dl, dr, D)      # noqa: E731
@@ -312,7 +316,7 @@ def main():
         "sgm_pass": 2 * 2 * vol_bytes,    # one direction on BOTH volumes (one launch advances left + right)
         "sgm_first_pass": 2 * 2 * vol_bytes,
     }
-    traffic = {} if args.exact else traffic_table(args.config)
+    traffic = traffic_table(args.config)
     rooflines = {}
     for k, b in algo.items():
         if k in stages:
@@ -333,15 +337,20 @@ def main():
         "value": round(value, 2), "unit": "Mdisparities/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if (args.exact or args.library_features) else
+        "dtype": "f32" if lib_features and (args.exact or args.library_features) else
+        "f32 (split-f16 operands: 22-bit products, float32 accumulate, in the conv features)" if args.exact else
         "f32 (split-f16 operands: 22-bit products, float32 accumulate, in the conv features and the cost volume)",
         "data": "synthetic",
         "config": {"workload": "%s: %dx%d synthetic stereo pair, D=%d, one pair per GPU" % (args.config, W, H, D),
-                   "variant": "bit-exact (every stage after the conv features bit-identical to the reference's NumPy)"
+                   "variant": ("bit-exact (every stage after the conv features bit-identical to the reference's NumPy)"
+                               if lib_features else
+                               "bit-exact stages behind split-operand features (every stage after the conv features "
+                               "bit-identical to the reference's NumPy GIVEN those features; see `parity` for the "
+                               "distance to the run with library features)")
                    if args.exact else
                    "fast (split-f16 MFMA features + cost volume, separable float64-prefix CBCA): index-exact WTA, final "
                    "map <= 0.05 px and >= 98.5 % of the pixels within 1e-3 px of the bit-exact variant (see `parity`)",
-                   "features": "float32 library convolutions (MIOpen)" if (args.exact or args.library_features) else
+                   "features": "float32 library convolutions (MIOpen)" if lib_features else
                    "split-operand f16 MFMA convolutions (float32 in/out, 3 products per multiply, float32 accumulate; "
                    "measured 5e-7 from a float64 evaluation vs 2.5e-7 for the library path: profiles/parity_features_split_r02.json)",
                    "launch": "one hipGraph replay per pair" if use_graph else "kernel by kernel",

@@ -65,6 +65,12 @@ parser.add_argument("--fast", action="store_true",
                          "<= 2e-6; CBCA through float64 prefix sums, <= 1e-6 per iteration) - about 13x faster.  "
                          "Without it every stage after the conv features is bit-identical to the reference's NumPy code")
 parser.add_argument("--exact", action="store_true", help="(default; kept for compatibility) the bit-exact variants")
+parser.add_argument("--features", choices=("library", "split_f16"), default=None,
+                    help="conv feature path, independent of --fast: 'library' = PyTorch-ROCm float32 convolutions (the "
+                         "default without --fast), 'split_f16' = the hand-written matrix-core stack (float32 in / out, "
+                         "operands as two f16 parts; the default with --fast).  'split_f16' without --fast keeps every "
+                         "stage after the features bit-identical to the reference given those features and saves the "
+                         "library's 1.7 ms per 750x500 pair")
 parser.add_argument("--pairs_in_flight", type=int, default=1,
                     help="stereo pairs matched concurrently on this GPU, each on its own HIP stream with its own "
                          "workspace.  The kernels of a KITTI-sized or smaller pair do not fill 256 CUs (a 256x256x64 "
@@ -152,7 +158,8 @@ def main(argv=None):
         net, hyper_parameters(args),
         cv_mode=hip.MCCNN_CV_MFMA if args.fast else hip.MCCNN_CV_EXACT,
         cbca_order=hip.MCCNN_CBCA_SEPARABLE if args.fast else hip.MCCNN_CBCA_REFERENCE_ORDER,
-        features="split_f16" if args.fast and args.patch_size >= 5 else "miopen",
+        features="split_f16" if (args.features == "split_f16" or (args.fast and args.features is None))
+        and args.patch_size >= 5 else "miopen",
         extras=dict(both_view_support=args.paper_support_regions,
                     interpolation_directions=16 if args.paper_interpolation else 4,
                     occlusion_from_left=args.paper_interpolation, numpy1_promotion=args.numpy1_promotion)) for _ in range(in_flight)]
