@@ -88,6 +88,28 @@ template <> struct Vec<4> {
     }
     static __device__ __forceinline__ T div(const T &a, float n) { T v = {a.x / n, a.y / n, a.z / n, a.w / n}; return v; }
 };
+// three disparities per lane: D = 192 (KITTI) fills all 64 lanes instead of 48 of them, and the window is a quarter
+// smaller (123 registers: four waves per SIMD instead of three)
+template <> struct Vec<3> {
+    struct T { float x, y, z; };
+    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+    static __device__ __forceinline__ T load(__amdgpu_buffer_rsrc_t rs, int voff, unsigned soff)
+    {
+        const u32x3 u = __builtin_amdgcn_raw_buffer_load_b96(rs, voff, soff, 0);
+        T v;
+        v.x = __uint_as_float(u.x); v.y = __uint_as_float(u.y); v.z = __uint_as_float(u.z);
+        return v;
+    }
+    static __device__ __forceinline__ void store(T v, __amdgpu_buffer_rsrc_t rs, int voff, unsigned soff)
+    {
+        u32x3 u;
+        u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z);
+        buffer_store_b96<CBCA_HWD_NTS>(u, rs, voff, soff);
+    }
+    static __device__ __forceinline__ T zero() { T v = {0.f, 0.f, 0.f}; return v; }
+    static __device__ __forceinline__ void add(T &a, const T &w) { a.x += w.x; a.y += w.y; a.z += w.z; }
+    static __device__ __forceinline__ T div(const T &a, float n) { T v = {a.x / n, a.y / n, a.z / n}; return v; }
+};
 template <> struct Vec<2> {
     struct T { float x, y; };
     static __device__ __forceinline__ T load(__amdgpu_buffer_rsrc_t rs, int voff, unsigned soff)
@@ -380,7 +402,9 @@ static int launch(const Jobs &jobs, int D, int H, int W, hipStream_t s)
 #ifdef CBCA_HWD_VPL
     const int vpl = CBCA_HWD_VPL;
 #else
-    const int vpl = Dp > 128 ? 4 : 2;
+    // 2 disparities per lane up to 128, 3 where that fills the lanes exactly (Dp a multiple of 3 up to 192: a lane
+    // must not straddle two pixels), 4 per lane and 256-disparity chunks otherwise
+    const int vpl = Dp <= 128 ? 2 : (Dp <= 192 && Dp % 3 == 0) ? 3 : 4;
 #endif
     const int nchunks = cdiv(Dp, 64 * vpl);
     const int band_rows = cdiv(cdiv(H, 8), hw::K * CBCA_HWD_WPB) * hw::K * CBCA_HWD_WPB;
@@ -390,6 +414,8 @@ static int launch(const Jobs &jobs, int D, int H, int W, hipStream_t s)
     const dim3 grid(8 * (band_rows / (hw::K * CBCA_HWD_WPB)), ngroups, nchunks * jobs.n), block(64 * CBCA_HWD_WPB);
     if (vpl == 4)
         hipLaunchKernelGGL(cbca_hwd_kernel<4>, grid, block, 0, s, jobs, Dp, H, W, nchunks, band_rows);
+    else if (vpl == 3)
+        hipLaunchKernelGGL(cbca_hwd_kernel<3>, grid, block, 0, s, jobs, Dp, H, W, nchunks, band_rows);
     else
         hipLaunchKernelGGL(cbca_hwd_kernel<2>, grid, block, 0, s, jobs, Dp, H, W, nchunks, band_rows);
     return check_launch("mccnn_cbca_iter_hwd");

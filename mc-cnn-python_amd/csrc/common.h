@@ -36,6 +36,12 @@ __device__ __forceinline__ void buffer_store_b128(V4 v, __amdgpu_buffer_rsrc_t r
     __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, soff, AUX);
     asm volatile("s_nop 0" ::"v"(v));
 }
+template <int AUX, typename V3>   // the 12-byte form is a "more than 8 bytes" store as well
+__device__ __forceinline__ void buffer_store_b96(V3 v, __amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b96(v, rs, voff, soff, AUX);
+    asm volatile("s_nop 0" ::"v"(v));
+}
 #endif
 
 #define MCCNN_REQUIRE(cond, code, ...)        \
