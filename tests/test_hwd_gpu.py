@@ -47,10 +47,12 @@ def test_golden_cbca_pixel_major_bit_exact(sd, golden_cases):
 
 
 @pytest.mark.parametrize("H,W,D", [(45, 100, 20), (64, 127, 33), (100, 70, 8), (7, 5, 3), (30, 13, 2), (21, 64, 130),
-                                   (16, 75, 256), (12, 50, 400), (3, 200, 64)])
+                                   (16, 75, 256), (12, 50, 400), (3, 200, 64), (24, 70, 192), (10, 40, 178),
+                                   (10, 40, 150)])
 def test_oracle_cbca_pixel_major_ragged_shapes(sd, H, W, D):
     """Widths that are not a multiple of the pixel group (or smaller than one), heights below the arm limit, one and two
-    256-disparity chunks, D not a multiple of 4: against the CPU checker, 2 iterations."""
+    256-disparity chunks, D not a multiple of 4, the three-disparities-per-lane path (padded D a multiple of 3 in
+    129 .. 192: 130, 178, 192) and its neighbour that is not (150): against the CPU checker, 2 iterations."""
     import oracle as o
     import synthetic
     rng = np.random.default_rng(H * 1000 + W)
