@@ -119,14 +119,22 @@ struct SgmParams {
 constexpr float kInf = __builtin_huge_valf();
 typedef uint32_t sgm_u32x4 __attribute__((ext_vector_type(4)));
 
-// NG = number of 256-disparity groups per lane (lane l of group g owns d = 256g + 4l .. +3), PF = steps in flight,
-// FULL = every lane of every group holds four real disparities (D == 256*NG): no tail masking at all.
+// NG = number of 64 * VPL-disparity groups per lane (lane l of group g owns d = 64 VPL g + VPL l .. + VPL - 1), PF =
+// steps in flight, FULL = every lane of every group holds VPL real disparities (D == 64 * VPL * NG): no tail masking.
+// VPL = 4 disparities per lane (16-byte accesses); VPL = 3 (12-byte accesses, one group) serves 129 .. 192 disparities
+// whose padded count is a multiple of 3 - KITTI's D = 192 then runs on all 64 lanes instead of 48.
 // All memory traffic goes through raw buffer instructions: per-lane byte offset (constant for the whole scanline) +
 // wave-uniform step offset in an SGPR, so a step spends no VALU on addresses; lanes past the disparity range get an
 // out-of-range offset (loads return 0, stores are dropped) instead of a branch.
-template <int NG, int PF, bool FULL>
+typedef uint32_t sgm_u32x3 __attribute__((ext_vector_type(3)));
+template <int VPL> struct SgmVec {
+    float v[VPL];
+};
+template <int NG, int PF, bool FULL, int VPL = 4>
 __global__ __launch_bounds__(64) void sgm_pass_kernel(const SgmParams P)
 {
+    static_assert(VPL == 4 || (VPL == 3 && NG == 1), "three disparities per lane: one group only");
+    typedef SgmVec<VPL> vec;
     const SgmJob J = P.job[blockIdx.y];
     const int lane = threadIdx.x;
     const int line = blockIdx.x;
@@ -154,42 +162,56 @@ __global__ __launch_bounds__(64) void sgm_pass_kernel(const SgmParams P)
     int dlane[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        dlane[g] = g * 256 + lane * 4;
+        dlane[g] = g * 64 * VPL + lane * VPL;
         const bool act = FULL || dlane[g] < D;
         voff[g] = act ? 4 * dlane[g] : kDrop;
+        // four flag bytes: x = w + d .. w + d + 3 (right volume) or x = w - d - 3 .. w - d (left volume); with three
+        // disparities per lane the fourth byte is fetched and ignored
         boff[g] = act ? P.pad + (J.dsign > 0 ? dlane[g] : -dlane[g] - 3) : kDrop;
     }
     const int shl = J.dsign > 0 ? 0 : 24;  // byte j of the packed flags sits at bit 8*j (dsign>0) or 8*(3-j)
     const int sdir = J.dsign > 0 ? 8 : -8;
 
-    auto mask_tail = [&](float4 v, int g) {  // disparities >= D behave as +inf (never win a min; their stores are pads)
+    auto mask_tail = [&](vec v, int g) {  // disparities >= D behave as +inf (never win a min; their stores are pads)
         if (!FULL) {
             const int d = dlane[g];
-            if (d + 0 >= D) v.x = kInf;
-            if (d + 1 >= D) v.y = kInf;
-            if (d + 2 >= D) v.z = kInf;
-            if (d + 3 >= D) v.w = kInf;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j)
+                if (d + j >= D) v.v[j] = kInf;
         }
         return v;
     };
+    auto vec_min = [&](const vec &v) {
+        float r = v.v[0];
+#pragma unroll
+        for (int j = 1; j < VPL; ++j) r = vmin(r, v.v[j]);
+        return r;
+    };
     auto pos = [&](int t) { return (unsigned)(fwd ? t : nsteps - t); };
     auto load_vol = [&](int g, int t) {
-        const sgm_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs_vol, voff[g], pos(t) * vstride, kNT);
-        return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+        vec r;
+        if constexpr (VPL == 4) {
+            const sgm_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs_vol, voff[g], pos(t) * vstride, kNT);
+            r.v[0] = __uint_as_float(u.x); r.v[1] = __uint_as_float(u.y); r.v[2] = __uint_as_float(u.z); r.v[3] = __uint_as_float(u.w);
+        } else {
+            const sgm_u32x3 u = __builtin_amdgcn_raw_buffer_load_b96(rs_vol, voff[g], pos(t) * vstride, kNT);
+            r.v[0] = __uint_as_float(u.x); r.v[1] = __uint_as_float(u.y); r.v[2] = __uint_as_float(u.z);
+        }
+        return r;
     };
 
-    float4 prev[NG];
+    vec prev[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) prev[g] = mask_tail(load_vol(g, 0), g);
     float m;
     {
         float lm = kInf;
 #pragma unroll
-        for (int g = 0; g < NG; ++g) lm = vmin(lm, vmin(vmin(prev[g].x, prev[g].y), vmin(prev[g].z, prev[g].w)));
+        for (int g = 0; g < NG; ++g) lm = vmin(lm, vec_min(prev[g]));
         m = wave_min(lm);
     }
 
-    float4 cbuf[PF][NG];
+    vec cbuf[PF][NG];
     uint32_t fbuf[PF][NG];
     uint32_t abuf[PF];
     auto issue = [&](int slot, int t) {
@@ -213,55 +235,45 @@ __global__ __launch_bounds__(64) void sgm_pass_kernel(const SgmParams P)
             // class a+b: b = 0 -> index a, b = 1 -> index a+1
             const float p1lo = a ? P.p1[1] : P.p1[0], p1hi = a ? P.p1[2] : P.p1[1];
             const float p2lo = a ? P.p2[1] : P.p2[0], p2hi = a ? P.p2[2] : P.p2[1];
-            float4 nw[NG];
+            vec nw[NG];
             float lm = kInf;
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                const float4 pv = prev[g];
+                const vec pv = prev[g];
                 // neighbours d-1 / d+1 across lanes; the ends of the disparity range see +inf (pf:552,566)
-                float below = dpp_mov<0x138>(kInf, pv.w);  // wave_shr:1 - lane l gets lane l-1
-                float above = dpp_mov<0x130>(kInf, pv.x);  // wave_shl:1 - lane l gets lane l+1
+                float below = dpp_mov<0x138>(kInf, pv.v[VPL - 1]);  // wave_shr:1 - lane l gets lane l-1
+                float above = dpp_mov<0x130>(kInf, pv.v[0]);        // wave_shl:1 - lane l gets lane l+1
                 if (NG > 1) {
                     if (g > 0 && lane == 0)
-                        below = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(prev[g > 0 ? g - 1 : 0].w), 63));
+                        below = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(prev[g > 0 ? g - 1 : 0].v[VPL - 1]), 63));
                     if (g + 1 < NG && lane == 63)
-                        above = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(prev[g + 1 < NG ? g + 1 : g].x), 0));
+                        above = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(prev[g + 1 < NG ? g + 1 : g].v[0]), 0));
                 }
-                const float4 c = mask_tail(cbuf[k][g], g);
+                const vec c = mask_tail(cbuf[k][g], g);
                 const uint32_t fb = fbuf[k][g];
-                const bool b0 = (fb >> shl) & 1u, b1 = (fb >> (shl + sdir)) & 1u, b2 = (fb >> (shl + 2 * sdir)) & 1u,
-                           b3 = (fb >> (shl + 3 * sdir)) & 1u;
-                float4 o;
-                {
-                    const float q1 = b0 ? p1hi : p1lo, q2 = b0 ? p2hi : p2lo;
-                    const float best = vmin(vmin3(pv.x, below + q1, pv.y + q1), m + q2);
-                    const float s = c.x + best;
-                    o.x = s - m;
-                }
-                {
-                    const float q1 = b1 ? p1hi : p1lo, q2 = b1 ? p2hi : p2lo;
-                    const float best = vmin(vmin3(pv.y, pv.x + q1, pv.z + q1), m + q2);
-                    const float s = c.y + best;
-                    o.y = s - m;
-                }
-                {
-                    const float q1 = b2 ? p1hi : p1lo, q2 = b2 ? p2hi : p2lo;
-                    const float best = vmin(vmin3(pv.z, pv.y + q1, pv.w + q1), m + q2);
-                    const float s = c.z + best;
-                    o.z = s - m;
-                }
-                {
-                    const float q1 = b3 ? p1hi : p1lo, q2 = b3 ? p2hi : p2lo;
-                    const float best = vmin(vmin3(pv.w, pv.z + q1, above + q1), m + q2);
-                    const float s = c.w + best;
-                    o.w = s - m;
+                vec o;
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) {
+                    const bool bj = (fb >> (shl + j * sdir)) & 1u;
+                    const float q1 = bj ? p1hi : p1lo, q2 = bj ? p2hi : p2lo;
+                    const float lo = j > 0 ? pv.v[j > 0 ? j - 1 : 0] : below;
+                    const float hi = j + 1 < VPL ? pv.v[j + 1 < VPL ? j + 1 : j] : above;
+                    const float best = vmin(vmin3(pv.v[j], lo + q1, hi + q1), m + q2);
+                    const float sum = c.v[j] + best;
+                    o.v[j] = sum - m;
                 }
                 nw[g] = o;
-                sgm_u32x4 ou;
-                ou.x = __float_as_uint(o.x); ou.y = __float_as_uint(o.y);
-                ou.z = __float_as_uint(o.z); ou.w = __float_as_uint(o.w);
-                buffer_store_b128<kNT>(ou, rs_vol, voff[g], pos(t) * vstride);
-                lm = vmin(lm, vmin(vmin(o.x, o.y), vmin(o.z, o.w)));
+                if constexpr (VPL == 4) {
+                    sgm_u32x4 ou;
+                    ou.x = __float_as_uint(o.v[0]); ou.y = __float_as_uint(o.v[1]);
+                    ou.z = __float_as_uint(o.v[2]); ou.w = __float_as_uint(o.v[3]);
+                    buffer_store_b128<kNT>(ou, rs_vol, voff[g], pos(t) * vstride);
+                } else {
+                    sgm_u32x3 ou;
+                    ou.x = __float_as_uint(o.v[0]); ou.y = __float_as_uint(o.v[1]); ou.z = __float_as_uint(o.v[2]);
+                    buffer_store_b96<kNT>(ou, rs_vol, voff[g], pos(t) * vstride);
+                }
+                lm = vmin(lm, vec_min(o));
             }
             issue(k, min(t + PF, nsteps));   // past the end: a harmless re-read of the last line (keeps the code branch-free)
             m = wave_min(lm);
@@ -620,6 +632,10 @@ extern "C" int mccnn_sgm_pass(const float *image_left, const float *image_right,
 #endif
     if (D == 256)
         hipLaunchKernelGGL((sgm_pass_kernel<1, 16, true>), grid, block, 0, s, P);
+    else if (D == 192)                                   // three disparities per lane: all 64 lanes, no tail masks
+        hipLaunchKernelGGL((sgm_pass_kernel<1, SGM_PF_PARTIAL, true, 3>), grid, block, 0, s, P);
+    else if (D > 128 && D < 192 && P.Dp % 3 == 0)
+        hipLaunchKernelGGL((sgm_pass_kernel<1, SGM_PF_PARTIAL, false, 3>), grid, block, 0, s, P);
     else if (D < 256)
         hipLaunchKernelGGL((sgm_pass_kernel<1, SGM_PF_PARTIAL, false>), grid, block, 0, s, P);
     else if (D == 512)
