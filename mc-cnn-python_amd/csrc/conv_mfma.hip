@@ -398,10 +398,10 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
                     const int i = it * 64 + lane, pl = i >> 4, part = i & 15, p = hf * EPX + pl;
                     const w4 o = *reinterpret_cast<const w4 *>(epi + pl * EPITCH + part * 16);
                     const bool ok = row < Ho && tx0 + p < Wo;
-                    // plain builtin, not common.h's buffer_store_b128: the data comes out of LDS (the gfx950 store-data hazard
-                    // needs VALU-written data right in front of the store, tools/probe/storehazard.hip), and a volatile asm
-                    // here would act as a scheduling barrier inside the hand-ordered tile loop
-                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, ok ? p * REC + part * 16 : 0x7ffffff0, so, 0);
+                    // padded store (common.h): the compiler reuses o's registers for the next piece's index right behind
+                    // the store, and the gfx950 store-data hazard also exists - at 4e-7 per store instead of 1e-2 - when
+                    // the data came out of LDS (tools/probe/storehazard.hip)
+                    buffer_store_b128<0>(o, rs_out, ok ? p * REC + part * 16 : 0x7ffffff0, so);
                 }
             }
             __builtin_amdgcn_wave_barrier();

@@ -1,11 +1,12 @@
 """CPU: the built gfx950 code is free of the store-data hazard the compiler does not pad (tools/probe/storehazard.hip).
 
-Measured on MI355X: when a VALU instruction writes the first data register of a `buffer_store_dwordx4` in the issue
-slot right behind the store, and the store's data was itself produced by VALU instructions, the store picks up the
-NEW value in lanes 12-15 of every 16 (about 1 % of the stores) - if the store's soffset is an SGPR.  LLVM pads only the
-immediate-soffset form.  One wait state is enough, and data that came out of LDS / memory is not affected.
-cbca_hwd_kernel's epilogue once produced wrong first components that way; common.h's buffer_store_b128 adds the wait
-state.  This test disassembles lib/libmccnn_hip.so and fails on any store that matches the measured conditions."""
+Measured on MI355X: when a VALU instruction writes the first data register of a `buffer_store_dwordx4` / `dwordx3` in
+the issue slot right behind the store, the store picks up the NEW value in lanes 12-15 of every 16 - about 1 % of the
+stores when the data was itself produced by VALU instructions, 4e-7 of them when it came out of LDS - if the store's
+soffset is an SGPR.  LLVM pads only the immediate-soffset form.  One wait state is enough; 8- and 4-byte stores are
+not affected.  cbca_hwd_kernel's epilogue once produced wrong first components that way; common.h's
+buffer_store_b128 / _b96 add the wait state.  This test disassembles lib/libmccnn_hip.so and fails on any 12- or
+16-byte buffer store with an SGPR soffset whose data registers are written in the very next instruction."""
 import os
 import re
 import shutil
@@ -47,15 +48,7 @@ def scan(lines):
         nxt = lines[i + 1][1].split()
         if not (_is_valu(nxt[0]) and len(nxt) > 1 and _regs(nxt[1]) & data):
             continue                                           # at least one wait state behind the store
-        # who wrote the data registers last?  a memory / LDS load is fine, a VALU instruction is the measured hazard
-        for j in range(i - 1, max(i - 400, -1), -1):
-            if lines[j][0] != kernel:
-                break
-            t = lines[j][1].split()
-            if len(t) > 1 and _regs(t[1]) & data:
-                if _is_valu(t[0]):
-                    hits.append("%s: '%s' right behind '%s' (data written by '%s')" % (kernel, lines[i + 1][1], text, lines[j][1]))
-                break
+        hits.append("%s: '%s' right behind '%s'" % (kernel, lines[i + 1][1], text))
     return hits
 
 
@@ -86,7 +79,9 @@ def test_scanner_finds_the_measured_pattern():
     assert scan(padded) == []
     from_lds = [("k", "ds_read_b128 v[0:3], v163"), ("k", "s_waitcnt lgkmcnt(0)"),
                 ("k", "buffer_store_dwordx4 v[0:3], v8, s[40:43], s99 offen"), ("k", "v_or_b32_e32 v0, s69, v150")]
-    assert scan(from_lds) == []
+    assert len(scan(from_lds)) == 1                            # rarer (4e-7 per store), not safe
+    narrow = [bad[0], ("k", "buffer_store_dwordx2 v[0:1], v124, s[0:3], s40 offen"), bad[2]]
+    assert scan(narrow) == []
     imm = [bad[0], ("k", "buffer_store_dwordx4 v[0:3], v124, s[0:3], 0 offen"), bad[2]]
     assert scan(imm) == []                                     # the compiler's own two wait states cover this form
 

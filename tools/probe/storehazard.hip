@@ -20,6 +20,15 @@ constexpr int NS = 10;
                  : [x] "v"(x), [y] "v"(y), [p] "v"(poison), [vo] "v"(voff), [rs] "s"(rs), [so] "s"(soff)       \
                  : "v20", "v21", "v22", "v23", "memory")
 
+// narrower stores: 8 bytes (below LLVM's "more than 8 bytes" rule) and 12 bytes
+#define STORE_SEQ_N(WIDTH, REGS, NOPS)                                                                      \
+    asm volatile("v_mov_b32 v20, %[x]\n v_mov_b32 v21, %[y]\n v_mov_b32 v22, %[y]\n v_mov_b32 v23, %[y]\n"   \
+                 "buffer_store_" WIDTH " " REGS ", %[vo], %[rs], %[so] offen\n" NOPS                           \
+                 "v_mov_b32 v20, %[p]\n"                                                                       \
+                 :                                                                                             \
+                 : [x] "v"(x), [y] "v"(y), [p] "v"(poison), [vo] "v"(voff), [rs] "s"(rs), [so] "s"(soff)       \
+                 : "v20", "v21", "v22", "v23", "memory")
+
 // the data registers come out of LDS (ds_read_b128 + wait) instead of out of VALU instructions: conv3x3_split's epilogue
 #define STORE_SEQ_LDS(NOPS)                                                                                \
     asm volatile("ds_read_b128 v[20:23], %[la]\n s_waitcnt lgkmcnt(0)\n"                                    \
@@ -59,6 +68,10 @@ __global__ __launch_bounds__(64) void k(float *out, int stride_bytes)
         if (MODE == 6) STORE_SEQ("s_nop 1\n", " nt", "%[so]");
         if (MODE == 7) STORE_SEQ("s_nop 7\n", " nt", "%[so]");
         if (MODE == 8) STORE_SEQ("s_nop 7\n s_nop 7\n", " nt", "%[so]");
+        if (MODE == 11) STORE_SEQ_N("dwordx2", "v[20:21]", "");
+        if (MODE == 12) STORE_SEQ_N("dwordx3", "v[20:22]", "");
+        if (MODE == 13) STORE_SEQ_N("dword", "v20", "");
+        if (MODE == 14) STORE_SEQ_N("dwordx3", "v[20:22]", "s_nop 0\n");
         if (MODE == 9 || MODE == 10) {
             const int laddr = (int)(uintptr_t)(__attribute__((address_space(3))) float *)lds + i * 1024 + threadIdx.x * 16;
             if (MODE == 9) STORE_SEQ_LDS("");
@@ -100,6 +113,10 @@ int main()
         run<8>("sgpr soffset, nt, 16 wait states", blocks);
         run<9>("data from ds_read, sgpr soffset, 0 wait states", blocks);
         run<10>("data from ds_read, sgpr soffset, 1 wait state", blocks);
+        run<11>("dwordx2, sgpr soffset, 0 wait states", blocks);
+        run<12>("dwordx3, sgpr soffset, 0 wait states", blocks);
+        run<14>("dwordx3, sgpr soffset, 1 wait state", blocks);
+        run<13>("dword, sgpr soffset, 0 wait states", blocks);
     }
     return 0;
 }
