@@ -154,6 +154,16 @@ int mccnn_cbca_iter_hwd_pair(const float *in_left, float *out_left, const mccnn_
                              const float *in_right, float *out_right, const mccnn_support_t *support_right, int D,
                              int H, int W, int L, mccnn_stream_t stream);
 
+/* The LAST iteration of an aggregation fused with a7 (pf:239-272): like mccnn_cbca_iter_hwd_pair, and the first strict
+ * minimum over d of every pixel of the two results goes to disparity_left / disparity_right ([H][W] float32, -1 where
+ * no disparity wins), exactly what mccnn_wta_hwd returns on the stored volumes.  store_right = 0 leaves out_right
+ * unwritten (it may then be NULL): match.py needs the final right volume for nothing but its WTA.  One chunk of
+ * disparities per wave: D <= 256 (MCCNN_E_UNSUPPORTED beyond; run mccnn_wta_hwd then). */
+int mccnn_cbca_iter_hwd_pair_wta(const float *in_left, float *out_left, const mccnn_support_t *support_left,
+                                 const float *in_right, float *out_right, const mccnn_support_t *support_right, int D,
+                                 int H, int W, int L, float *disparity_left, float *disparity_right, int store_right,
+                                 mccnn_stream_t stream);
+
 /* ---- layout changes between DHW and HWD ------------------------------------------------------------------- */
 int mccnn_hwd_pitch(int D); /* Dp: D rounded up to a multiple of 4 (16-byte rows) */
 int mccnn_dhw_to_hwd(const float *dhw, float *hwd, int D, int H, int W, mccnn_stream_t stream);

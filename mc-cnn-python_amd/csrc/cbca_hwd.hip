@@ -211,12 +211,46 @@ __device__ __forceinline__ void load_window(typename Vec<VPL>::T (&win)[NW], wm_
     }
 }
 
+// wave-wide reductions of the WTA (also used by the fused last iteration below)
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp_i(int old, int src)
+{
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ float wave_min_f(float x)
+{
+    // lanes without a source keep their own value (old = x)
+    auto step = [](float v, int o) { return fminf(v, __int_as_float(o)); };
+    x = step(x, dpp_i<0xB1>(__float_as_int(x), __float_as_int(x)));         // quad_perm [1,0,3,2]
+    x = step(x, dpp_i<0x4E>(__float_as_int(x), __float_as_int(x)));         // quad_perm [2,3,0,1]
+    x = step(x, dpp_i<0x141>(__float_as_int(x), __float_as_int(x)));        // row_half_mirror
+    x = step(x, dpp_i<0x140>(__float_as_int(x), __float_as_int(x)));        // row_mirror
+    x = step(x, dpp_i<0x142, 0xA>(__float_as_int(x), __float_as_int(x)));   // row_bcast:15
+    x = step(x, dpp_i<0x143, 0xC>(__float_as_int(x), __float_as_int(x)));   // row_bcast:31
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+__device__ __forceinline__ int wave_min_i(int x)
+{
+    x = min(x, dpp_i<0xB1>(x, x));
+    x = min(x, dpp_i<0x4E>(x, x));
+    x = min(x, dpp_i<0x141>(x, x));
+    x = min(x, dpp_i<0x140>(x, x));
+    x = min(x, dpp_i<0x142, 0xA>(x, x));
+    x = min(x, dpp_i<0x143, 0xC>(x, x));
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
 // One launch aggregates up to two volumes of the same shape (left and right view, each with its own support plane).
 struct Jobs {
     const float *in[2];
     float *out[2];
     const Support *sup[2];
     int n;
+    // fused WTA of the last iteration (WTA kernels only): the first strict minimum over d of every output pixel
+    // (pf:245-254) goes to disp[job]; a volume whose store[job] is 0 is not written at all
+    float *disp[2];
+    int store[2];
+    int D;
 };
 
 // A wave owns a patch of K x G anchors: rows y0 .. y0 + K - 1 (y0 a multiple of K), columns x0 .. x0 + G - 1.
@@ -255,7 +289,7 @@ __device__ __forceinline__ void walk_anchor_rows(typename Vec<VPL>::T (&acc)[K][
     }
 }
 
-template <int VPL>
+template <int VPL, bool WTA = false>
 __global__ __launch_bounds__(64 * CBCA_HWD_WPB, CBCA_HWD_MINW) void cbca_hwd_kernel(const Jobs jobs, int Dp, int H, int W, int nchunks, int band_rows)
 {
     typedef typename Vec<VPL>::T vf;
@@ -387,14 +421,36 @@ __global__ __launch_bounds__(64 * CBCA_HWD_WPB, CBCA_HWD_MINW) void cbca_hwd_ker
         // range check, so the loop needs no per-column validity (their counts are whatever word follows: never used);
         // a row below the image gets an empty descriptor instead of a branch (a branch here lets the compiler sink that
         // row's divisions behind it, back between the stores)
+        const bool wr = y < H && (!WTA || (job ? jobs.store[1] : jobs.store[0]) != 0);
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-            out + ((size_t)y * W + x0) * Dp, 0, y < H ? (int)((unsigned)min(G, W - x0) * pix) : 0, 0x00020000);
+            out + ((size_t)y * W + x0) * Dp, 0, wr ? (int)((unsigned)min(G, W - x0) * pix) : 0, 0x00020000);
 #pragma unroll
         for (int j = 0; j < G; ++j) Vec<VPL>::store(res[k][j], rs_out, voff, (unsigned)j * pix);
     }
+    if constexpr (WTA) {
+        // a7 fused into the last iteration: exactly wta_hwd_kernel's two reductions on the values just stored
+        // (the minimum, then the lowest index among the lanes that hold it; NaN never wins; -1 when nothing does)
+        float *const dsp = job ? jobs.disp[1] : jobs.disp[0];
+        const int D = jobs.D;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                float best = __builtin_huge_valf();
+                int bd = -1;
+                const float *c = &res[k][j].x;
+#pragma unroll
+                for (int q = 0; q < VPL; ++q)
+                    if (d0 + q < D && c[q] < best) { best = c[q]; bd = d0 + q; }
+                const float mn = wave_min_f(best);
+                const int idx = wave_min_i((best == mn && bd >= 0) ? bd : 0x7fffffff);
+                if (lane == 0 && y0 + k < H && x0 + j < W)
+                    dsp[(size_t)(y0 + k) * W + x0 + j] = idx == 0x7fffffff ? -1.f : (float)idx;
+            }
+    }
 }
 
-static int launch(const Jobs &jobs, int D, int H, int W, hipStream_t s)
+static int launch(const Jobs &jobs, int D, int H, int W, hipStream_t s, bool wta = false)
 {
     const int Dp = mccnn_hwd_pitch(D);
     MCCNN_REQUIRE((size_t)(2 * R + K) * W * Dp * 4 < ((size_t)1 << 31), MCCNN_E_UNSUPPORTED,
@@ -412,46 +468,27 @@ static int launch(const Jobs &jobs, int D, int H, int W, hipStream_t s)
     MCCNN_REQUIRE(ngroups <= 65535 && nchunks * jobs.n <= 65535, MCCNN_E_UNSUPPORTED,
                   "mccnn_cbca_iter_hwd: %dx%dx%d exceeds the grid", W, H, D);
     const dim3 grid(8 * (band_rows / (hw::K * CBCA_HWD_WPB)), ngroups, nchunks * jobs.n), block(64 * CBCA_HWD_WPB);
-    if (vpl == 4)
-        hipLaunchKernelGGL(cbca_hwd_kernel<4>, grid, block, 0, s, jobs, Dp, H, W, nchunks, band_rows);
+    if (wta) {
+        MCCNN_REQUIRE(nchunks == 1, MCCNN_E_UNSUPPORTED,
+                      "mccnn_cbca_iter_hwd_pair_wta: D=%d spans more than one chunk of a wave (use mccnn_wta_hwd)", D);
+        if (vpl == 4)
+            hipLaunchKernelGGL((cbca_hwd_kernel<4, true>), grid, block, 0, s, jobs, Dp, H, W, nchunks, band_rows);
+        else if (vpl == 3)
+            hipLaunchKernelGGL((cbca_hwd_kernel<3, true>), grid, block, 0, s, jobs, Dp, H, W, nchunks, band_rows);
+        else
+            hipLaunchKernelGGL((cbca_hwd_kernel<2, true>), grid, block, 0, s, jobs, Dp, H, W, nchunks, band_rows);
+    } else if (vpl == 4)
+        hipLaunchKernelGGL((cbca_hwd_kernel<4, false>), grid, block, 0, s, jobs, Dp, H, W, nchunks, band_rows);
     else if (vpl == 3)
-        hipLaunchKernelGGL(cbca_hwd_kernel<3>, grid, block, 0, s, jobs, Dp, H, W, nchunks, band_rows);
+        hipLaunchKernelGGL((cbca_hwd_kernel<3, false>), grid, block, 0, s, jobs, Dp, H, W, nchunks, band_rows);
     else
-        hipLaunchKernelGGL(cbca_hwd_kernel<2>, grid, block, 0, s, jobs, Dp, H, W, nchunks, band_rows);
+        hipLaunchKernelGGL((cbca_hwd_kernel<2, false>), grid, block, 0, s, jobs, Dp, H, W, nchunks, band_rows);
     return check_launch("mccnn_cbca_iter_hwd");
 }
 
 // ---- a7 on the pixel-major volume: first strict minimum over d (pf:245-254) ----------------------------------------
 // One pixel per wave step, 4 disparities per lane and 256-disparity group; the lowest index among equal minima is
 // found by a second reduction over the candidates' indices.  8 pixels (8 KiB of loads) in flight per wave.
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ int dpp_i(int old, int src)
-{
-    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
-}
-__device__ __forceinline__ float wave_min_f(float x)
-{
-    // lanes without a source keep their own value (old = x)
-    auto step = [](float v, int o) { return fminf(v, __int_as_float(o)); };
-    x = step(x, dpp_i<0xB1>(__float_as_int(x), __float_as_int(x)));         // quad_perm [1,0,3,2]
-    x = step(x, dpp_i<0x4E>(__float_as_int(x), __float_as_int(x)));         // quad_perm [2,3,0,1]
-    x = step(x, dpp_i<0x141>(__float_as_int(x), __float_as_int(x)));        // row_half_mirror
-    x = step(x, dpp_i<0x140>(__float_as_int(x), __float_as_int(x)));        // row_mirror
-    x = step(x, dpp_i<0x142, 0xA>(__float_as_int(x), __float_as_int(x)));   // row_bcast:15
-    x = step(x, dpp_i<0x143, 0xC>(__float_as_int(x), __float_as_int(x)));   // row_bcast:31
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
-}
-__device__ __forceinline__ int wave_min_i(int x)
-{
-    x = min(x, dpp_i<0xB1>(x, x));
-    x = min(x, dpp_i<0x4E>(x, x));
-    x = min(x, dpp_i<0x141>(x, x));
-    x = min(x, dpp_i<0x140>(x, x));
-    x = min(x, dpp_i<0x142, 0xA>(x, x));
-    x = min(x, dpp_i<0x143, 0xC>(x, x));
-    return __builtin_amdgcn_readlane(x, 63);
-}
-
 __global__ __launch_bounds__(256) void wta_hwd_kernel(const float *__restrict__ vol, int D, int Dp, long N,
                                                       float *__restrict__ disp, int per_wave)
 {
@@ -540,7 +577,7 @@ extern "C" int mccnn_cbca_iter_hwd(const float *in_hwd, float *out_hwd, const mc
     MCCNN_REQUIRE(L >= 1 && L <= 14, MCCNN_E_UNSUPPORTED,
                   "mccnn_cbca_iter_hwd: L=%d outside [1,14] (use mccnn_cbca_iter on the plane-major volume)", L);
     if (const int rc = check_support_record(support, H, W, L, "mccnn_cbca_iter_hwd")) return rc;
-    const hw::Jobs jobs = {{in_hwd, nullptr}, {out_hwd, nullptr}, {support, nullptr}, 1};
+    const hw::Jobs jobs = {{in_hwd, nullptr}, {out_hwd, nullptr}, {support, nullptr}, 1, {nullptr, nullptr}, {1, 1}, D};
     return hw::launch(jobs, D, H, W, (hipStream_t)stream);
 }
 
@@ -560,8 +597,33 @@ extern "C" int mccnn_cbca_iter_hwd_pair(const float *in_left, float *out_left, c
     if (rc) return rc;
     rc = check_support_record(support_right, H, W, L, "mccnn_cbca_iter_hwd_pair");
     if (rc) return rc;
-    const hw::Jobs jobs = {{in_left, in_right}, {out_left, out_right}, {support_left, support_right}, 2};
+    const hw::Jobs jobs = {{in_left, in_right}, {out_left, out_right}, {support_left, support_right}, 2,
+                           {nullptr, nullptr}, {1, 1}, D};
     return hw::launch(jobs, D, H, W, (hipStream_t)stream);
+}
+
+extern "C" int mccnn_cbca_iter_hwd_pair_wta(const float *in_left, float *out_left, const mccnn_support_t *support_left,
+                                            const float *in_right, float *out_right, const mccnn_support_t *support_right,
+                                            int D, int H, int W, int L, float *disparity_left, float *disparity_right,
+                                            int store_right, mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(in_left && out_left && support_left && in_right && support_right && disparity_left && disparity_right,
+                  MCCNN_E_INVALID, "mccnn_cbca_iter_hwd_pair_wta: null pointer");
+    MCCNN_REQUIRE(out_right || !store_right, MCCNN_E_INVALID, "mccnn_cbca_iter_hwd_pair_wta: store_right without out_right");
+    MCCNN_REQUIRE(in_left != out_left && in_right != out_right && out_left != out_right && in_left != out_right &&
+                      in_right != out_left,
+                  MCCNN_E_INVALID, "mccnn_cbca_iter_hwd_pair_wta: outputs must not alias an input or each other");
+    MCCNN_REQUIRE(D > 0 && H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_cbca_iter_hwd_pair_wta: non-positive size");
+    MCCNN_REQUIRE(L >= 1 && L <= 14, MCCNN_E_UNSUPPORTED, "mccnn_cbca_iter_hwd_pair_wta: L=%d outside [1,14]", L);
+    int rc = check_support_record(support_left, H, W, L, "mccnn_cbca_iter_hwd_pair_wta");
+    if (rc) return rc;
+    rc = check_support_record(support_right, H, W, L, "mccnn_cbca_iter_hwd_pair_wta");
+    if (rc) return rc;
+    // a volume that is not stored still needs a valid (never dereferenced) base for its empty descriptors
+    const hw::Jobs jobs = {{in_left, in_right}, {out_left, store_right ? out_right : out_left},
+                           {support_left, support_right}, 2, {disparity_left, disparity_right}, {1, store_right ? 1 : 0}, D};
+    return hw::launch(jobs, D, H, W, (hipStream_t)stream, true);
 }
 
 extern "C" int mccnn_wta_hwd(const float *vol_hwd, int D, int H, int W, float *disparity, mccnn_stream_t stream)

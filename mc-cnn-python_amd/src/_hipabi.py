@@ -42,6 +42,7 @@ SIGNATURES = {
     "mccnn_cbca_iter_both": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mccnn_cbca_iter_hwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mccnn_cbca_iter_hwd_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mccnn_cbca_iter_hwd_pair_wta": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "mccnn_wta_hwd": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mccnn_subpixel_hwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "mccnn_hwd_pitch": (_i, [_i]),

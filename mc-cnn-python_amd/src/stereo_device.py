@@ -277,9 +277,17 @@ def cbca_hwd(vol, tmp, support, D, iterations, distance_threshold, timer=None):
     return src, dst
 
 
-def cbca_hwd_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, D, iterations, distance_threshold, timer=None):
+def cbca_hwd_wta_max_d():
+    """Largest D whose last aggregation iteration can carry the WTA (one chunk of disparities per wave)."""
+    return 256
+
+
+def cbca_hwd_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, D, iterations, distance_threshold, timer=None,
+                  wta_out=None, store_right=True):
     """cbca_hwd() on the left and the right volume, one launch per iteration (mccnn_cbca_iter_hwd_pair).
-    Returns ((result_l, spare_l), (result_r, spare_r))."""
+    Returns ((result_l, spare_l), (result_r, spare_r)).  wta_out = (disp_l, disp_r) [H,W] float32: the last iteration
+    also writes the WTA disparities of both results (mccnn_cbca_iter_hwd_pair_wta; D <= cbca_hwd_wta_max_d());
+    store_right=False then leaves the right result volume unwritten (its returned tensor holds stale data)."""
     H, W, Dp = vol_l.shape
     assert Dp == hwd_pitch(D)
     for t in (tmp_l, vol_r, tmp_r):
@@ -290,11 +298,24 @@ def cbca_hwd_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, D, iteration
     lib = hip.load()
     (sl, dl), (sr, dr) = (vol_l, tmp_l), (vol_r, tmp_r)
     timer = timer or _NO_TIMER
-    for _ in range(int(iterations)):
+    n = int(iterations)
+    if wta_out is not None and (n < 1 or D > cbca_hwd_wta_max_d()):
+        raise ValueError("cbca_hwd_pair: the fused WTA needs at least one iteration and D <= %d" % cbca_hwd_wta_max_d())
+    for it in range(n):
         timer.start("cbca_iter_hwd_pair")
-        hip.check(lib.mccnn_cbca_iter_hwd_pair(hip.ptr(sl), hip.ptr(dl), hip.ptr(support_l), hip.ptr(sr), hip.ptr(dr),
-                                               hip.ptr(support_r), int(D), H, W, int(distance_threshold),
-                                               hip.stream()), "mccnn_cbca_iter_hwd_pair")
+        if wta_out is not None and it == n - 1:
+            for t in wta_out:
+                if tuple(t.shape) != (H, W) or t.dtype != torch.float32 or not t.is_contiguous():
+                    raise ValueError("cbca_hwd_pair: wta_out must be two contiguous float32 [H,W] tensors")
+            hip.check(lib.mccnn_cbca_iter_hwd_pair_wta(hip.ptr(sl), hip.ptr(dl), hip.ptr(support_l), hip.ptr(sr),
+                                                       hip.ptr(dr), hip.ptr(support_r), int(D), H, W,
+                                                       int(distance_threshold), hip.ptr(wta_out[0]), hip.ptr(wta_out[1]),
+                                                       1 if store_right else 0, hip.stream()),
+                      "mccnn_cbca_iter_hwd_pair_wta")
+        else:
+            hip.check(lib.mccnn_cbca_iter_hwd_pair(hip.ptr(sl), hip.ptr(dl), hip.ptr(support_l), hip.ptr(sr), hip.ptr(dr),
+                                                   hip.ptr(support_r), int(D), H, W, int(distance_threshold),
+                                                   hip.stream()), "mccnn_cbca_iter_hwd_pair")
         timer.stop()
         sl, dl, sr, dr = dl, sl, dr, sr
     return (sl, dl), (sr, dr)
@@ -659,14 +680,21 @@ class StereoMatcher(object):
                             hp["sgm_D"], hp["sgm_V"], ws["scratch"], timer)
             if keep is not None:
                 keep["sgm"] = (hwd_to_dhw(lh, D), hwd_to_dhw(rh, D))
+            # the last iteration carries the WTA of both results (and leaves the right volume, which nothing else
+            # reads, unwritten) when a wave holds all disparities of a pixel
+            fuse = int(hp["cbca_num_iterations2"]) >= 1 and D <= cbca_hwd_wta_max_d()
             (lh, lt), (rh, rt) = cbca_hwd_pair(lh, lt, sup_l, rh, rt, sup_r, D, hp["cbca_num_iterations2"],
-                                               hp["cbca_distance"], timer)
+                                               hp["cbca_distance"], timer, wta_out=(m[0], m[1]) if fuse else None,
+                                               store_right=keep is not None)
             if keep is not None:
                 keep["cbca2"] = (hwd_to_dhw(lh, D), hwd_to_dhw(rh, D))
-            timer.start("wta")
-            dl = wta_hwd(lh, D, out=m[0])
-            dr = wta_hwd(rh, D, out=m[1])
-            timer.stop()
+            if fuse:
+                dl, dr = m[0], m[1]
+            else:
+                timer.start("wta")
+                dl = wta_hwd(lh, D, out=m[0])
+                dr = wta_hwd(rh, D, out=m[1])
+                timer.stop()
             sub = lambda di: subpixel_hwd(di, lh, D, out=m[3], numpy1_promotion=ex["numpy1_promotion"])   # noqa: E731
         else:
             def aggregate(vol, tmp, own, other, n, side):

@@ -119,6 +119,54 @@ def test_cbca_pixel_major_pair_launch_equals_single_launches(sd, H, W, D, iters)
     assert torch.equal(pl[:, :, :D], ql[:, :, :D]) and torch.equal(pr[:, :, :D], qr[:, :, :D])
 
 
+@pytest.mark.parametrize("H,W,D,iters", [(70, 300, 5, 1), (40, 33, 64, 2), (33, 47, 192, 1), (21, 64, 130, 2),
+                                         (64, 100, 256, 3), (9, 12, 3, 1), (16, 40, 250, 1)])
+def test_last_iteration_with_fused_wta_equals_iteration_then_wta(sd, H, W, D, iters):
+    """mccnn_cbca_iter_hwd_pair_wta: same volumes and the same disparities as the unfused launches - on ties across
+    lanes, NaN / inf costs and all-NaN pixels too; with store_right = 0 the right output volume is not touched."""
+    import synthetic
+    L, R, _, _, _ = synthetic.make_pair(H, W, min(16, W - 2), seed=17)
+    sl, sr = sd.cross_arms_pair(dev(L[:, :, 0]), dev(R[:, :, 0]), 0.02, 14)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    Dp = sd.hwd_pitch(D)
+    a = torch.round((torch.rand((H, W, Dp), device="cuda", generator=g) - 0.5) * 8) / 8      # coarse values: many ties
+    b = torch.rand((H, W, Dp), device="cuda", generator=g) - 0.5
+    a[3, 5, :] = float("nan"); a[4, 6, D // 2] = float("nan"); b[2, 1, 0] = float("-inf"); b[5, 7, :] = float("inf")
+    (pl, _), (pr, _) = sd.cbca_hwd_pair(a.clone(), torch.empty_like(a), sl, b.clone(), torch.empty_like(b), sr, D, iters, 14)
+    wl, wr = sd.wta_hwd(pl, D), sd.wta_hwd(pr, D)
+    fl, fr = torch.full((H, W), 123.0, device="cuda"), torch.full((H, W), 123.0, device="cuda")
+    (ql, _), (qr, _) = sd.cbca_hwd_pair(a.clone(), torch.empty_like(a), sl, b.clone(), torch.empty_like(b), sr, D, iters,
+                                        14, wta_out=(fl, fr))
+    def same(x, y):
+        return torch.equal(torch.nan_to_num(x, nan=777.0), torch.nan_to_num(y, nan=777.0))
+    assert same(ql[:, :, :D], pl[:, :, :D]) and same(qr[:, :, :D], pr[:, :, :D])
+    assert torch.equal(fl, wl) and torch.equal(fr, wr)
+    # right volume left unwritten
+    fl2, fr2 = torch.empty_like(fl), torch.empty_like(fr)
+    ping, pong = b.clone(), torch.full_like(b, -7.0)
+    (_, _), (rr, spare) = sd.cbca_hwd_pair(a.clone(), torch.empty_like(a), sl, ping, pong, sr, D, iters, 14,
+                                           wta_out=(fl2, fr2), store_right=False)
+    assert torch.equal(fl2, wl) and torch.equal(fr2, wr)
+    if iters == 1:
+        assert bool((rr == -7.0).all()), "store_right = 0 must leave the right output volume untouched"
+
+
+def test_fused_wta_refuses_more_than_one_chunk(sd):
+    import _hipabi as hip
+    H, W, D = 8, 16, 300
+    img = torch.zeros((H, W), device="cuda")
+    sup = sd.cross_arms(img, 0.02, 14)
+    Dp = sd.hwd_pitch(D)
+    a, b = torch.zeros((H, W, Dp), device="cuda"), torch.zeros((H, W, Dp), device="cuda")
+    c, d = torch.zeros((H, W, Dp), device="cuda"), torch.zeros((H, W, Dp), device="cuda")
+    dl, dr = torch.zeros((H, W), device="cuda"), torch.zeros((H, W), device="cuda")
+    rc = hip.load().mccnn_cbca_iter_hwd_pair_wta(hip.ptr(a), hip.ptr(b), hip.ptr(sup), hip.ptr(c), hip.ptr(d), hip.ptr(sup),
+                                                 D, H, W, 14, hip.ptr(dl), hip.ptr(dr), 1, hip.stream())
+    assert rc == hip.MCCNN_E_UNSUPPORTED
+    with pytest.raises(ValueError):
+        sd.cbca_hwd_pair(a, b, sup, c, d, sup, D, 1, 14, wta_out=(dl, dr))
+
+
 def test_golden_wta_and_subpixel_pixel_major(sd, golden_cases):
     for name, g in golden_cases:
         for side in ("l", "r"):
