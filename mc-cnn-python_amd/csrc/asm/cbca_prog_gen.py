@@ -1,0 +1,553 @@
+#!/usr/bin/env python3
+"""Generator of the gfx950 assembly of `cbca_prog_kernel`: a4 cost_volume_aggregation
+(/root/reference/src/process_functional.py:149-163) in the reference's summation order on pixel-major volumes, run as a
+PRE-COMPILED PER-PATCH PROGRAM.
+
+Why assembly, and why a program.  cbca_hwd_kernel (cbca_hwd.hip, round 3) walks the support regions of a K x G patch of
+anchors with scalar code: per region row it decodes arms, tests which anchors take part, dispatches the window loads
+slot by slot and guards every chain element with a scalar bit test + branch - ~240 scalar instructions and ~25 taken
+branches per row for ~120 vector adds, in 165 registers (a statically indexed 31-slot register window), three waves
+per SIMD.  None of that control depends on the disparity or on the iteration: it is a function of the image alone and
+is the same for all 18 aggregation iterations of a pair and for every disparity chunk.  So it is compiled ONCE per
+image (cbca_prog_build, cbca_prog.hip) into a linear program per patch, and the kernel here is a threaded-code
+interpreter of that program:
+
+  op (32 bit) = [15:0] byte offset of its handler from `code_base`, [31:16] parameter (lands in M0)
+  LOAD  n, p   n consecutive pixels ending at pixel index p (relative to the patch's first region row) -> window
+               slots n-1 .. 0: computed entry into a straight line of buffer_load_dwordx{VPL}, then s_waitcnt vmcnt(0)
+  WAIT  k      s_waitcnt vmcnt(k) (not emitted by the current builder)
+  ADD   s, n   one arm of one anchor column (for anchor row 0, 1 or both): n window slots added in order into the
+               anchors' accumulators.  The window is addressed RELATIVELY (VGPR index mode, M0 = parameter), so one
+               straight line of v_add_f32 per (column, anchor set, direction) serves every arm: descending arms
+               (self, left 1, 2, ...) enter a line whose register numbers fall, ascending arms (right 1, 2, ...) one
+               whose numbers rise, at the block that leaves exactly n adds to the end of the line; M0 shifts the line
+               onto the slots of this arm.  No test or branch per element, no instruction for anchors that sit a row out.
+  REFILL       the next 64 ops (ops live one per lane in a VGPR; v_readlane fetches op i)
+  END          divide by the region sizes, store (pf:161)
+
+Every op ends in the same 7-instruction dispatcher (fetch, decode, s_setpc).  The same additions in the same order per
+(pixel, disparity) as the reference: bit-exact.  Relative addressing shrinks the window from 31 statically indexed
+slots to the W the program is built for (12): 96 registers, five waves per SIMD.
+
+The file doubles as the description of the code layout for the program builder (`layout()` -> cbca_prog_layout.h) and
+for the instruction-level simulator the CPU tests run the kernel on (tools/asm_sim.py).
+
+    python cbca_prog_gen.py --vpl 4 -o cbca_prog_v4.s --header cbca_prog_layout_v4.h
+"""
+import argparse
+import re
+import sys
+
+R = 13                     # longest arm (distance threshold L <= 14)
+KDROP = 0x7ffffff0         # byte offset past every buffer: the range check drops the access
+M0_SRC1 = 0x2000           # M0[15:12] = 2: VGPR index mode applies to SRC1 only (the window operand)
+
+
+class Ins:
+    __slots__ = ("op", "args", "mods", "comment")
+
+    def __init__(self, op, args, mods=None, comment=None):
+        self.op, self.args, self.mods, self.comment = op, list(args), dict(mods or {}), comment
+
+    def __repr__(self):
+        return self.render()
+
+    def render(self):
+        if self.op == "label":
+            return "%s:" % self.args[0]
+        a = ", ".join(_fmt(x) for x in self.args)
+        m = ""
+        for k, v in self.mods.items():
+            if v is True:
+                m += " " + k
+            elif v is not None and v is not False:
+                m += " %s:%s" % (k, v)
+        s = "  %s %s%s" % (self.op, a, m)
+        if self.comment:
+            s = "%-72s // %s" % (s, self.comment)
+        return s
+
+    def size(self):
+        return ins_size(self)
+
+
+def _fmt(x):
+    if isinstance(x, int):
+        return str(x) if -16 <= x <= 64 else "0x%x" % (x & 0xffffffff)
+    if isinstance(x, float):
+        return repr(x)
+    return str(x)
+
+
+SOPP = {"s_waitcnt", "s_branch", "s_cbranch_scc0", "s_cbranch_scc1", "s_cbranch_vccz", "s_cbranch_vccnz", "s_nop",
+        "s_endpgm", "s_set_gpr_idx_off", "s_barrier", "s_cbranch_execz"}
+SOPK = {"s_movk_i32"}
+SMEM = {"s_load_dword", "s_load_dwordx2", "s_load_dwordx4", "s_load_dwordx8", "s_load_dwordx16"}
+VOP3 = {"v_readlane_b32", "v_fma_f32", "v_div_scale_f32", "v_div_fmas_f32", "v_div_fixup_f32", "v_mul_lo_u32",
+        "v_mad_u32_u24", "v_cndmask_b32_e64", "v_cmp_lt_f32_e64", "v_cmp_eq_f32_e64", "v_cmp_gt_u32_e64",
+        "v_min3_f32", "v_lshl_add_u32"}
+MUBUF = {"buffer_load_dword", "buffer_load_dwordx2", "buffer_load_dwordx3", "buffer_load_dwordx4",
+         "buffer_store_dword", "buffer_store_dwordx2", "buffer_store_dwordx3", "buffer_store_dwordx4"}
+FLOAT_INLINE = {0.0, 0.5, 1.0, 2.0, 4.0, -0.5, -1.0, -2.0, -4.0}
+
+
+def _is_literal(x):
+    if isinstance(x, int):
+        return not (-16 <= x <= 64)
+    if isinstance(x, float):
+        return x not in FLOAT_INLINE
+    return False
+
+
+def ins_size(i):
+    """Encoded size in bytes (checked against llvm-objdump by the build, see check_layout)."""
+    if i.op == "label" or i.op.startswith("pseudo_"):
+        return 0
+    if i.op in SOPP or i.op in SOPK:
+        return 4
+    if i.op in SMEM or i.op in VOP3 or i.op in MUBUF:
+        return 8
+    if i.mods.get("dpp"):
+        return 8
+    if i.op == "s_set_gpr_idx_on":
+        return 4
+    return 8 if any(_is_literal(a) or (isinstance(a, str) and "code_base" in a) for a in i.args) else 4
+
+
+class Params:
+    def __init__(self, vpl=4, K=2, G=5, W=12, NB=1, PF=0, wta=False, debug=0):
+        assert K == 2, "anchor-set lines are written for K = 2"
+        self.VPL, self.K, self.G, self.W, self.NB, self.PF, self.wta, self.debug = vpl, K, G, W, NB, PF, wta, debug
+        self.MAXD = min(W, R + 1)                   # longest descending run one op can carry (self + left arm)
+        self.MAXA = min(W, R)                       # longest ascending run
+        self.RS = vpl + (vpl & 1)                   # registers per slot / accumulator: gfx950 wants even-aligned tuples
+        self.nacc = K * G * self.RS
+        # VGPR map: accumulators, four service registers, window
+        self.v_voff, self.v_progA, self.v_progB, self.v_lane4 = self.nacc, self.nacc + 1, self.nacc + 2, self.nacc + 3
+        self.PHYS_WIN = max(self.nacc + 4, self.RS * (self.MAXA - 1))
+        self.PHYS_WIN = (self.PHYS_WIN + 3) & ~3
+        self.nvgpr = self.PHYS_WIN + NB * W * self.RS      # NB windows: the next one loads under the current one's adds
+        self.NWAIT = W + 1                          # WAIT handlers 0 .. W
+
+    def acc(self, k, j, c=0):
+        return (k * self.G + j) * self.RS + c
+
+    def name(self):
+        return "mccnn_cbca_prog_v%d%s" % (self.VPL, "_wta" if self.wta else "")
+
+
+# ---- scalar register map ------------------------------------------------------------------------------------------
+S = dict(
+    karg=0,            # s[0:1] kernarg segment
+    bx=2, by=3, bz=4,  # workgroup ids
+    # kernarg block 0 (0x00..0x3f): in0 in1 out0 out1 prog0 prog1 sup0 sup1
+    ka=8,              # s[8:23]
+    # kernarg block 1 (0x40..0x5f): Dp H W nchunks band_rows band_groups prog_stride_bytes ngroups
+    Dp=24, H=25, W=26, nchunks=27, band_rows=28, band_groups=29, prog_stride=30, ngroups=31,
+    # kernarg block 2 (0x60..0x7f): disp0 disp1 (wta) D store1 pad pad
+    disp=32,           # s[32:35]
+    D=36, store1=37,
+    y0=40, x0=41, job=42, chunk=43,
+    inp=44,            # s[44:45]
+    outp=46,           # s[46:47]
+    supp=48,           # s[48:49]
+    progp=50,          # s[50:51]
+    rs_in=52,          # s[52:55]
+    rs_prog=56,        # s[56:59]
+    pix=60, so=61, i=62, op=63, t=64,
+    base=66,           # s[66:67]
+    pc=68,             # s[68:69]
+    safe_m0=70, progoff=71,
+    t0=72, t1=73, t2=74, t3=75, t4=76, t5=77,
+    rs_out=80,         # s[80:83]
+    cnt=84,            # s[84 : 84 + K*G]
+    dispp=96,          # s[96:97]
+    dump=98, pfoff=99,
+    pfa=100,           # s[100:101]
+)
+NSGPR = 102
+
+
+def sreg(n, cnt=1):
+    return "s%d" % n if cnt == 1 else "s[%d:%d]" % (n, n + cnt - 1)
+
+
+def vreg(n, cnt=1):
+    return "v%d" % n if cnt == 1 else "v[%d:%d]" % (n, n + cnt - 1)
+
+
+class Gen:
+    def __init__(self, P):
+        self.P = P
+        self.ins = []
+        self.labels = {}
+
+    def e(self, op, *args, comment=None, **mods):
+        self.ins.append(Ins(op, args, mods, comment))
+
+    def label(self, name):
+        self.ins.append(Ins("label", [name]))
+
+    # -- the dispatcher every handler ends in -------------------------------------------------------------------------
+    def tail(self, wait=None):
+        """wait: an s_waitcnt that may sit behind the decode of the next op (the LOAD handler's vmcnt(0))."""
+        e = self.e
+        e("v_readlane_b32", sreg(S["op"]), vreg(self.P.v_progA), sreg(S["i"]))
+        e("s_add_u32", sreg(S["i"]), sreg(S["i"]), 1)
+        e("s_sext_i32_i16", sreg(S["t"]), sreg(S["op"]))
+        e("s_lshr_b32", "m0", sreg(S["op"]), 16)
+        e("s_add_u32", sreg(S["pc"]), sreg(S["base"]), sreg(S["t"]))
+        e("s_addc_u32", sreg(S["pc"] + 1), sreg(S["base"] + 1), 0)
+        if wait:
+            e("s_waitcnt", wait)
+        e("s_setpc_b64", sreg(S["pc"], 2))
+
+    def vload(self, dst, voff, rs, soff, **mods):
+        n = self.P.VPL
+        op = {1: "buffer_load_dword", 2: "buffer_load_dwordx2", 3: "buffer_load_dwordx3", 4: "buffer_load_dwordx4"}[n]
+        self.e(op, vreg(dst, n), vreg(voff), sreg(rs, 4), soff, offen=True, **mods)
+
+    def vstore(self, src, voff, rs, soff, **mods):
+        n = self.P.VPL
+        op = {1: "buffer_store_dword", 2: "buffer_store_dwordx2", 3: "buffer_store_dwordx3", 4: "buffer_store_dwordx4"}[n]
+        self.e(op, vreg(src, n), vreg(voff), sreg(rs, 4), soff, offen=True, **mods)
+
+    # -- kernel ----------------------------------------------------------------------------------------------------------
+    def build(self):
+        P, e = self.P, self.e
+        K, G, VPL, W = P.K, P.G, P.VPL, P.W
+        s = lambda n, c=1: sreg(S[n], c) if isinstance(n, str) else sreg(n, c)
+        self.label("entry")
+        e("s_load_dwordx16", s("ka", 16), s("karg", 2), 0x0)
+        e("s_load_dwordx8", s("Dp", 8), s("karg", 2), 0x40)
+        e("s_waitcnt", "lgkmcnt(0)")
+        # y0 = (bx & 7) * band_rows + (bx >> 3) * K ; patch row group = (bx & 7) * band_groups + (bx >> 3)
+        e("s_and_b32", s("t0"), s("bx"), 7)
+        e("s_lshr_b32", s("t1"), s("bx"), 3)
+        e("s_mul_i32", s("y0"), s("t0"), s("band_rows"))
+        e("s_mul_i32", s("t2"), s("t1"), K)
+        e("s_add_u32", s("y0"), s("y0"), s("t2"))
+        e("s_cmp_ge_i32", s("y0"), s("H"))
+        e("s_cbranch_scc1", "done")
+        e("s_mul_i32", s("t0"), s("t0"), s("band_groups"))
+        e("s_add_u32", s("t0"), s("t0"), s("t1"))                        # patch row group
+        e("s_mul_i32", s("t0"), s("t0"), s("ngroups"))
+        e("s_add_u32", s("t0"), s("t0"), s("by"), comment="patch index")
+        e("s_mul_i32", s("x0"), s("by"), G)
+        # job = bz >= nchunks, chunk = bz - job * nchunks; pick the job's pointers
+        e("s_cmp_ge_u32", s("bz"), s("nchunks"))
+        e("s_cselect_b32", s("job"), 1, 0)
+        e("s_cselect_b32", s("t1"), s("nchunks"), 0)
+        e("s_cselect_b64", s("inp", 2), sreg(S["ka"] + 2, 2), sreg(S["ka"] + 0, 2))
+        e("s_cselect_b64", s("outp", 2), sreg(S["ka"] + 6, 2), sreg(S["ka"] + 4, 2))
+        e("s_cselect_b64", s("progp", 2), sreg(S["ka"] + 10, 2), sreg(S["ka"] + 8, 2))
+        e("s_cselect_b64", s("supp", 2), sreg(S["ka"] + 14, 2), sreg(S["ka"] + 12, 2))
+        e("s_sub_u32", s("chunk"), s("bz"), s("t1"))
+        # program of this patch: one dword per lane, two 64-op chunks in flight
+        e("s_mul_hi_u32", s("t2"), s("t0"), s("prog_stride"))
+        e("s_mul_i32", s("t1"), s("t0"), s("prog_stride"))
+        e("s_add_u32", s("rs_prog"), s("progp"), s("t1"))
+        e("s_addc_u32", sreg(S["rs_prog"] + 1), sreg(S["progp"] + 1), s("t2"))
+        e("s_and_b32", sreg(S["rs_prog"] + 1), sreg(S["rs_prog"] + 1), 0xffff)
+        e("s_mov_b32", sreg(S["rs_prog"] + 2), s("prog_stride"))
+        e("s_mov_b32", sreg(S["rs_prog"] + 3), 0x00020000)
+        e("v_lshlrev_b32", vreg(P.v_lane4), 2, "v0", comment="lane * 4 (v0 becomes an accumulator)")
+        e("buffer_load_dword", vreg(P.v_progA), vreg(P.v_lane4), s("rs_prog", 4), 0, offen=True)
+        e("buffer_load_dword", vreg(P.v_progB), vreg(P.v_lane4), s("rs_prog", 4), 0, offen=True, offset=256)
+        e("s_movk_i32", s("progoff"), 512)
+        # pix = Dp * 4 ; voff = d0 * 4 with d0 = (chunk * 64 + lane) * VPL, or kDrop past the disparity range
+        e("s_lshl_b32", s("pix"), s("Dp"), 2)
+        e("s_lshl_b32", s("t1"), s("chunk"), 6)
+        vt = P.PHYS_WIN                                                 # a window register as scratch
+        e("v_add_u32", vreg(vt), s("t1"), "v0")
+        e("v_mul_u32_u24", vreg(vt), 4 * VPL, vreg(vt))
+        e("v_mov_b32", vreg(P.v_voff), KDROP)
+        e("v_cmp_gt_u32", "vcc", s("pix"), vreg(vt))
+        e("v_cndmask_b32", vreg(P.v_voff), vreg(P.v_voff), vreg(vt), "vcc")
+        if P.PF:
+            self.prefetch()
+        # input rows row0 .. row1 any arm of this patch can reach: descriptor base = in + row0 * W * pix
+        e("s_sub_u32", s("t0"), s("y0"), R)
+        e("s_max_i32", s("t0"), s("t0"), 0, comment="row0")
+        e("s_sub_u32", s("t3"), s("H"), 1)
+        e("s_add_u32", s("t1"), s("y0"), K - 1)
+        e("s_min_i32", s("t1"), s("t1"), s("t3"))
+        e("s_add_u32", s("t1"), s("t1"), R)
+        e("s_min_i32", s("t1"), s("t1"), s("t3"), comment="row1")
+        e("s_sub_u32", s("t1"), s("t1"), s("t0"))
+        e("s_add_u32", s("t1"), s("t1"), 1, comment="rows")
+        e("s_mul_i32", s("t2"), s("W"), s("pix"), comment="bytes per image row")
+        e("s_mul_i32", sreg(S["rs_in"] + 2), s("t1"), s("t2"))
+        e("s_mul_hi_u32", s("t4"), s("t0"), s("t2"))
+        e("s_mul_i32", s("t3"), s("t0"), s("t2"))
+        e("s_add_u32", s("rs_in"), s("inp"), s("t3"))
+        e("s_addc_u32", sreg(S["rs_in"] + 1), sreg(S["inp"] + 1), s("t4"))
+        e("s_and_b32", sreg(S["rs_in"] + 1), sreg(S["rs_in"] + 1), 0xffff)
+        e("s_mov_b32", sreg(S["rs_in"] + 3), 0x00020000)
+        for r in range(P.nacc):
+            e("v_mov_b32", vreg(r), 0)                                  # pf:156: the sum starts at 0
+        # code_base for the op offsets
+        e("s_getpc_b64", s("base", 2))
+        self.label("after_getpc")
+        e("s_add_u32", s("base"), s("base"), "code_base-after_getpc")
+        e("s_addc_u32", sreg(S["base"] + 1), sreg(S["base"] + 1), 0)
+        e("s_mov_b32", s("i"), 0)
+        e("s_mov_b32", s("safe_m0"), M0_SRC1)
+        e("s_waitcnt", "vmcnt(0)")
+        e("s_set_gpr_idx_on", s("i"), "gpr_idx(SRC1)", comment="index mode on for the whole program: M0 = 0x2000 | idx")
+        self.tail()
+
+        self.label("code_base")
+        # ---- ADD lines: (column j, anchor set 1 = row 0 / 2 = row 1 / 3 = both, direction) ---------------------------
+        self.lines = {}
+        for j in range(G):
+            for aset in (1, 2, 3):
+                for d, maxn in (("d", P.MAXD), ("a", P.MAXA)):
+                    name = "add_j%d_s%d_%s" % (j, aset, d)
+                    self.label(name)
+                    self.lines[(j, aset, d)] = name
+                    for blk in range(maxn, 0, -1):                       # block `blk` leaves blk adds to the end
+                        # descending: static slot blk - 1 (numbers fall along the line); ascending: 1 - blk (rise)
+                        slot = (blk - 1) if d == "d" else (1 - blk)
+                        for k in range(K):
+                            if aset & (1 << k):
+                                for c in range(VPL):
+                                    e("v_add_f32", vreg(P.acc(k, j, c)), vreg(P.acc(k, j, c)),
+                                      vreg(P.PHYS_WIN + P.RS * slot + c))
+                    self.tail()
+        # ---- LOAD: entry per (window, n) (parameter -> soffset), then the straight line of loads -----------------------
+        # one window: the handler ends with s_waitcnt vmcnt(0) behind the next op's decode; two windows: no wait here,
+        # the program says WAIT k (k = loads of the window that was requested last)
+        for b in range(P.NB):
+            for n in range(1, W + 1):
+                self.label("load_b%d_n%d" % (b, n))
+                e("s_mul_i32", s("so"), "m0", s("pix"))
+                e("s_mov_b32", "m0", s("safe_m0"))
+                if n != W:
+                    e("s_branch", "load_b%d_blk%d" % (b, n))
+            for n in range(W, 0, -1):
+                self.label("load_b%d_blk%d" % (b, n))
+                self.vload(P.PHYS_WIN + P.RS * (b * W + n - 1), P.v_voff, S["rs_in"], s("so"))
+                if n > 1:
+                    e("s_sub_u32", s("so"), s("so"), s("pix"))
+            self.tail(wait="vmcnt(0)" if P.NB == 1 else None)
+        # ---- WAIT k ----------------------------------------------------------------------------------------------------------
+        for k in range(P.NWAIT):
+            self.label("wait_%d" % k)
+            e("s_waitcnt", "vmcnt(%d)" % k)
+            self.tail()
+        # ---- REFILL -----------------------------------------------------------------------------------------------------------
+        self.label("refill")
+        e("s_waitcnt", "vmcnt(0)")
+        e("v_mov_b32", vreg(P.v_progA), vreg(P.v_progB))
+        e("buffer_load_dword", vreg(P.v_progB), vreg(P.v_lane4), s("rs_prog", 4), s("progoff"), offen=True)
+        e("s_add_u32", s("progoff"), s("progoff"), 256)
+        e("s_mov_b32", s("i"), 0)
+        self.tail()
+        # ---- END: pf:161 -------------------------------------------------------------------------------------------------------
+        self.label("end")
+        e("s_set_gpr_idx_off")
+        # region sizes of the K x G anchors (rows clamped to the image; words past the right edge are never used)
+        e("s_sub_u32", s("t3"), s("H"), 1)
+        for k in range(K):
+            e("s_add_u32", s("t0"), s("y0"), k)
+            e("s_min_i32", s("t0"), s("t0"), s("t3"))
+            e("s_mul_i32", s("t0"), s("t0"), s("W"))
+            e("s_add_u32", s("t0"), s("t0"), s("x0"))
+            e("s_lshl_b32", s("t0"), s("t0"), 2)                            # H * W * 4 < 2^31 (checked by the host)
+            e("s_add_u32", s("t4"), s("supp"), s("t0"))
+            e("s_addc_u32", s("t5"), sreg(S["supp"] + 1), 0)
+            for j in range(G):
+                e("s_load_dword", sreg(S["cnt"] + k * G + j), sreg(S["t4"], 2), 4 * j)
+        e("s_waitcnt", "lgkmcnt(0)")
+        T = P.PHYS_WIN                                                  # the window is dead: temporaries
+        for k in range(K if not (P.debug & 1) else 0):               # debug 1: raw sums instead of quotients
+            for j in range(G):
+                e("s_lshr_b32", s("t0"), sreg(S["cnt"] + k * G + j), 20)
+                e("v_cvt_f32_u32", vreg(T), s("t0"))
+                for c in range(VPL):
+                    num = P.acc(k, j, c)
+                    a, r, t, b, q = T + 1, T + 2, T + 3, T + 4, T + 5
+                    e("pseudo_div", vreg(num), vreg(T), 11)            # simulator: num /= den, skip the next 11
+                    e("v_div_scale_f32", vreg(a), sreg(S["t4"], 2), vreg(T), vreg(T), vreg(num))
+                    e("v_rcp_f32", vreg(r), vreg(a))
+                    # gfx940+ trans forwarding hazard: a VALU op may not read v_rcp's result in the next issue slot -
+                    # the independent second v_div_scale sits in between (and is >= 4 slots ahead of v_div_fmas' VCC read)
+                    e("v_div_scale_f32", vreg(b), "vcc", vreg(num), vreg(T), vreg(num))
+                    e("v_fma_f32", vreg(t), "-" + vreg(a), vreg(r), 1.0)
+                    e("v_fmac_f32", vreg(r), vreg(t), vreg(r))
+                    e("v_mul_f32", vreg(q), vreg(b), vreg(r))
+                    e("v_fma_f32", vreg(t), "-" + vreg(a), vreg(q), vreg(b))
+                    e("v_fmac_f32", vreg(q), vreg(t), vreg(r))
+                    e("v_fma_f32", vreg(a), "-" + vreg(a), vreg(q), vreg(b))
+                    e("v_div_fmas_f32", vreg(a), vreg(a), vreg(r), vreg(q))
+                    e("v_div_fixup_f32", vreg(num), vreg(a), vreg(T), vreg(num))
+        # stores: per anchor row a descriptor that ends with the row / the image (columns past the edge are dropped)
+        e("s_sub_u32", s("t5"), s("W"), s("x0"))
+        e("s_min_i32", s("t5"), s("t5"), G)
+        e("s_mul_i32", s("t5"), s("t5"), s("pix"), comment="bytes of the patch's columns inside the image")
+        e("s_mov_b32", sreg(S["rs_out"] + 3), 0x00020000)
+        for k in range(K):
+            e("s_add_u32", s("t0"), s("y0"), k)
+            e("s_cmp_lt_i32", s("t0"), s("H"))
+            e("s_cselect_b32", sreg(S["rs_out"] + 2), s("t5"), 0)
+            if P.debug & 2:                                             # debug 2 (timing only): nothing is stored
+                e("s_mov_b32", sreg(S["rs_out"] + 2), 0)
+            e("s_mul_i32", s("t0"), s("t0"), s("W"))
+            e("s_add_u32", s("t0"), s("t0"), s("x0"))
+            e("s_mul_hi_u32", s("t2"), s("t0"), s("pix"))
+            e("s_mul_i32", s("t1"), s("t0"), s("pix"))
+            e("s_add_u32", s("rs_out"), s("outp"), s("t1"))
+            e("s_addc_u32", sreg(S["rs_out"] + 1), sreg(S["outp"] + 1), s("t2"))
+            e("s_and_b32", sreg(S["rs_out"] + 1), sreg(S["rs_out"] + 1), 0xffff)
+            e("s_mov_b32", s("so"), 0)
+            for j in range(G):
+                self.vstore(P.acc(k, j), P.v_voff, S["rs_out"], s("so"), nt=True)
+                e("s_nop", 0, comment="gfx950 store-data hazard (common.h)")
+                if j + 1 < G:
+                    e("s_add_u32", s("so"), s("so"), s("pix"))
+        self.label("done")
+        e("s_endpgm")
+        return self
+
+    def prefetch(self):
+        """L2 warm-up through the SCALAR cache path.  The vector memory pipe of a CU keeps ~32 KiB of requests in
+        flight, and a request that has to go to HBM holds its place four times as long as one that hits L2: the
+        first touch of every voxel is what most of that capacity is spent on.  Scalar loads travel another way
+        (scalar data cache -> L2), so every wave touches - one s_load_dword per 128-byte line, results discarded -
+        the K x G pixels PF columns to the right of its own: the waves that will need them first are dispatched a few
+        microseconds later on this XCD and then find them in L2."""
+        P, e = self.P, self.e
+        s = lambda n, c=1: sreg(S[n], c) if isinstance(n, str) else sreg(n, c)
+        e("s_add_u32", s("t0"), s("x0"), P.PF)
+        e("s_cmp_ge_i32", s("t0"), s("W"))
+        e("s_cbranch_scc1", "pf_done")
+        e("s_sub_u32", s("t5"), s("W"), s("t0"))
+        e("s_min_i32", s("t5"), s("t5"), P.G)
+        e("s_mul_i32", s("t5"), s("t5"), s("pix"), comment="bytes of the prefetched columns of one row")
+        for k in range(P.K):
+            e("s_add_u32", s("t1"), s("y0"), k)
+            e("s_cmp_ge_i32", s("t1"), s("H"))
+            e("s_cbranch_scc1", "pf_done")
+            e("s_mul_i32", s("t1"), s("t1"), s("W"))
+            e("s_add_u32", s("t1"), s("t1"), s("t0"))
+            e("s_mul_hi_u32", s("t3"), s("t1"), s("pix"))
+            e("s_mul_i32", s("t2"), s("t1"), s("pix"))
+            e("s_add_u32", s("pfa"), s("inp"), s("t2"))
+            e("s_addc_u32", sreg(S["pfa"] + 1), sreg(S["inp"] + 1), s("t3"))
+            e("s_mov_b32", s("pfoff"), 0)
+            self.label("pf_loop%d" % k)
+            e("s_load_dword", s("dump"), s("pfa", 2), s("pfoff"))
+            e("s_add_u32", s("pfoff"), s("pfoff"), 128)
+            e("s_cmp_lt_u32", s("pfoff"), s("t5"))
+            e("s_cbranch_scc1", "pf_loop%d" % k)
+        self.label("pf_done")
+
+    # ---- layout ----------------------------------------------------------------------------------------------------------
+    def offsets(self):
+        """label -> byte offset from `entry`."""
+        off, out = 0, {}
+        for i in self.ins:
+            if i.op == "label":
+                out[i.args[0]] = off
+            else:
+                off += i.size()
+        out["__end"] = off
+        return out
+
+    def layout(self):
+        P = self.P
+        o = self.offsets()
+        base = o["code_base"]
+        L = dict(VPL=P.VPL, RS=P.RS, K=P.K, G=P.G, W=P.W, MAXD=P.MAXD, MAXA=P.MAXA, R=R, NWAIT=P.NWAIT, BLK=4 * P.VPL,
+                 M0_SRC1=M0_SRC1, code_bytes=o["__end"], nvgpr=P.nvgpr)
+        L["add"] = {key: o[name] - base for key, name in self.lines.items()}
+        L["load"] = [[0] + [o["load_b%d_n%d" % (b, n)] - base for n in range(1, P.W + 1)] for b in range(P.NB)]
+        L["NB"] = P.NB
+        L["wait"] = [o["wait_%d" % k] - base for k in range(P.NWAIT)]
+        L["refill"] = o["refill"] - base
+        L["end"] = o["end"] - base
+        assert max(L["wait"] + [L["end"], L["refill"]]) < 32768, "op offsets are 16-bit signed"
+        return L
+
+    def render(self):
+        P = self.P
+        name = P.name()
+        out = ['.amdgcn_target "amdgcn-amd-amdhsa--gfx950"', ".text", ".globl %s" % name, ".p2align 8",
+               ".type %s,@function" % name, "%s:" % name]
+        for i in self.ins:
+            if i.op == "label":
+                out.append(".L%s_%s:" % (name, i.args[0]))
+            elif i.op.startswith("pseudo_"):
+                continue
+            else:
+                line = i.render()
+                # local labels: branch targets and the code_base difference
+                line = re.sub(r"\b(code_base|after_getpc|done|pf_done|pf_loop\d+|load_b\d+_blk\d+)\b", lambda m: ".L%s_%s" % (name, m.group(1)), line)
+                out.append(line)
+        kargs = 0x80 if P.wta else 0x60
+        out += [".Lfunc_end_%s:" % name, ".size %s, .Lfunc_end_%s-%s" % (name, name, name), "",
+                ".rodata", ".p2align 6", ".amdhsa_kernel %s" % name,
+                "  .amdhsa_group_segment_fixed_size 0", "  .amdhsa_private_segment_fixed_size 0",
+                "  .amdhsa_kernarg_size %d" % kargs, "  .amdhsa_user_sgpr_count 2",
+                "  .amdhsa_user_sgpr_kernarg_segment_ptr 1", "  .amdhsa_system_sgpr_workgroup_id_x 1",
+                "  .amdhsa_system_sgpr_workgroup_id_y 1", "  .amdhsa_system_sgpr_workgroup_id_z 1",
+                "  .amdhsa_system_vgpr_workitem_id 0", "  .amdhsa_next_free_vgpr %d" % P.nvgpr,
+                "  .amdhsa_next_free_sgpr %d" % NSGPR, "  .amdhsa_accum_offset %d" % ((P.nvgpr + 3) & ~3),
+                "  .amdhsa_reserve_vcc 1", "  .amdhsa_float_round_mode_32 0", "  .amdhsa_float_round_mode_16_64 0",
+                "  .amdhsa_float_denorm_mode_32 3", "  .amdhsa_float_denorm_mode_16_64 3", "  .amdhsa_dx10_clamp 1",
+                "  .amdhsa_ieee_mode 1", ".end_amdhsa_kernel", "",
+                ".amdgpu_metadata", "---", "amdhsa.version:", "  - 1", "  - 2", "amdhsa.kernels:",
+                "  - .name: %s" % name, "    .symbol: %s.kd" % name, "    .kernarg_segment_size: %d" % kargs,
+                "    .kernarg_segment_align: 8", "    .group_segment_fixed_size: 0", "    .private_segment_fixed_size: 0",
+                "    .wavefront_size: 64", "    .sgpr_count: %d" % (NSGPR + 6), "    .vgpr_count: %d" % P.nvgpr,
+                "    .agpr_count: 0", "    .max_flat_workgroup_size: 64", "    .args:"]
+        off = 0
+        while off < kargs:
+            out += ["      - .offset: %d" % off, "        .size: 8", "        .value_kind: by_value"]
+            off += 8
+        out += ["amdhsa.target: amdgcn-amd-amdhsa--gfx950", "...", ".end_amdgpu_metadata", ""]
+        return "\n".join(out)
+
+
+def header(L, P):
+    """cbca_prog_layout_v{VPL}.h: the code layout the program builder encodes ops against."""
+    v = P.VPL
+    pre = "CBCA_PROG_V%d_" % v
+    out = ["// generated by csrc/asm/cbca_prog_gen.py - do not edit", "#pragma once", "#include <stdint.h>"]
+    for k in ("VPL", "RS", "K", "G", "W", "NB", "MAXD", "MAXA", "NWAIT", "BLK", "M0_SRC1"):
+        out.append("#define %s%s %d" % (pre, k, L[k]))
+    out.append("#define %sREFILL %d" % (pre, L["refill"]))
+    out.append("#define %sEND %d" % (pre, L["end"]))
+    # add[j][aset-1][dir] = offset of the line's first block
+    rows = []
+    for j in range(P.G):
+        rows.append("{" + ", ".join("{%d, %d}" % (L["add"][(j, a, "d")], L["add"][(j, a, "a")]) for a in (1, 2, 3)) + "}")
+    out.append("#define %sADD_INIT {%s}" % (pre, ", ".join(rows)))
+    out.append("#define %sLOAD_INIT {%s}" % (pre, ", ".join("{" + ", ".join(str(x) for x in row) + "}" for row in L["load"])))
+    out.append("#define %sWAIT_INIT {%s}" % (pre, ", ".join(str(x) for x in L["wait"])))
+    return "\n".join(out) + "\n"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--vpl", type=int, default=4)
+    ap.add_argument("--w", type=int, default=12)
+    ap.add_argument("--nb", type=int, default=1)
+    ap.add_argument("--pf", type=int, default=0)
+    ap.add_argument("--wta", action="store_true")
+    ap.add_argument("-o", default=None)
+    ap.add_argument("--header", default=None)
+    a = ap.parse_args()
+    P = Params(vpl=a.vpl, W=a.w, NB=a.nb, PF=a.pf, wta=a.wta)
+    g = Gen(P).build()
+    if a.o:
+        open(a.o, "w").write(g.render())
+    if a.header:
+        open(a.header, "w").write(header(g.layout(), P))
+    if not a.o and not a.header:
+        sys.stdout.write(g.render())
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,395 @@
+"""Instruction-level simulator for the subset of the gfx950 ISA that csrc/asm/cbca_prog_gen.py emits.
+
+Test infrastructure (CPU): runs the generated kernel wave by wave on numpy so that the control flow, the register
+allocation, the relative (index-mode) window addressing, the program encoding and the waitcnt discipline are checked
+without a GPU.  It models what the kernel relies on and nothing more:
+  * SGPRs / VGPRs / M0 / SCC / VCC, wave64, EXEC always full
+  * VGPR index mode: M0[7:0] is added to the VGPR number of the operands M0[15:12] selects (bit 0 SRC0 ... bit 3 DST)
+  * raw buffer loads / stores with the range check on voffset + soffset + inst_offset against num_records
+  * outstanding vector loads: a VGPR with a load in flight may not be read before an s_waitcnt vmcnt(k) retires it
+  * `pseudo_div` markers (one correctly rounded float32 division instead of the v_div_scale ... v_div_fixup sequence)
+"""
+import re
+import struct
+
+import numpy as np
+
+MASK32 = 0xffffffff
+
+
+class SimError(RuntimeError):
+    pass
+
+
+class Memory:
+    """Flat fake device memory: named allocations at 64-bit addresses."""
+
+    def __init__(self):
+        self.allocs = []
+        self.next = 0x7f0000000000
+
+    def alloc(self, arr):
+        a = np.ascontiguousarray(arr).view(np.uint8).reshape(-1).copy()
+        addr = self.next
+        self.allocs.append((addr, a))
+        self.next = (addr + a.size + 0xfff + 0x10000) & ~0xfff
+        return addr
+
+    def _find(self, addr, n):
+        for base, a in self.allocs:
+            if base <= addr and addr + n <= base + a.size:
+                return a, addr - base
+        raise SimError("access of %d bytes at 0x%x outside every allocation" % (n, addr))
+
+    def read(self, addr, n):
+        a, o = self._find(addr, n)
+        return a[o:o + n]
+
+    def write(self, addr, data):
+        a, o = self._find(addr, len(data))
+        a[o:o + len(data)] = data
+
+    def get(self, addr, dtype, count):
+        return self.read(addr, count * np.dtype(dtype).itemsize).view(dtype).copy()
+
+
+_RE_S = re.compile(r"^s(\d+)$")
+_RE_SR = re.compile(r"^s\[(\d+):(\d+)\]$")
+_RE_V = re.compile(r"^(-?)v(\d+)$")
+_RE_VR = re.compile(r"^v\[(\d+):(\d+)\]$")
+
+
+def f2u(x):
+    return struct.unpack("<I", struct.pack("<f", x))[0]
+
+
+class Wave:
+    def __init__(self, gen, mem, code_addr=0x7e00fffff000):
+        self.ins = [i for i in gen.ins]
+        self.mem = mem
+        self.code_addr = code_addr
+        # byte offset -> instruction index; label -> index
+        self.by_off, self.labels, off = {}, {}, 0
+        for n, i in enumerate(self.ins):
+            if i.op == "label":
+                self.labels[i.args[0]] = n
+            else:
+                if off not in self.by_off:
+                    self.by_off[off] = n
+                off += i.size()
+        self.off_of = {}
+        off = 0
+        for n, i in enumerate(self.ins):
+            self.off_of[n] = off
+            if i.op != "label":
+                off += i.size()
+        self.label_off = {k: self.off_of[v] for k, v in self.labels.items()}
+
+    def reset(self):
+        self.s = [0] * 128
+        self.v = np.zeros((256, 64), np.uint32)
+        self.m0 = 0
+        self.scc = 0
+        self.vcc = 0
+        self.idx_en = False
+        self.pending = []            # outstanding vector loads, oldest first: sets of VGPR numbers
+        self.pending_regs = {}
+        self.stats = dict(ins=0, valu=0, salu=0, vmem=0, smem=0, setpc=0)
+
+    # ---- operands ----------------------------------------------------------------------------------------------------
+    def rs(self, x):
+        """32-bit scalar source."""
+        if isinstance(x, int):
+            return x & MASK32
+        if isinstance(x, float):
+            return f2u(x)
+        if x == "m0":
+            return self.m0
+        if x == "vcc_lo":
+            return self.vcc & MASK32
+        m = _RE_S.match(x)
+        if m:
+            return self.s[int(m.group(1))]
+        if "code_base" in x:
+            a, b = x.split("-")
+            return (self.label_off[a] - self.label_off[b]) & MASK32
+        raise SimError("scalar source %r" % (x,))
+
+    def rs64(self, x):
+        if isinstance(x, int):
+            return x & 0xffffffffffffffff
+        if x == "vcc":
+            return self.vcc
+        m = _RE_SR.match(x)
+        if m:
+            lo = int(m.group(1))
+            return self.s[lo] | (self.s[lo + 1] << 32)
+        raise SimError("64-bit scalar source %r" % (x,))
+
+    def ws(self, x, val):
+        val &= MASK32
+        if x == "m0":
+            self.m0 = val
+            return
+        m = _RE_S.match(x)
+        if not m:
+            raise SimError("scalar destination %r" % (x,))
+        self.s[int(m.group(1))] = val
+
+    def ws64(self, x, val):
+        if x == "vcc":
+            self.vcc = val & 0xffffffffffffffff
+            return
+        m = _RE_SR.match(x)
+        lo = int(m.group(1))
+        self.s[lo] = val & MASK32
+        self.s[lo + 1] = (val >> 32) & MASK32
+
+    def _vidx(self, n, which):
+        """VGPR number after index mode (which: 0 src0, 1 src1, 2 src2, 3 dst)."""
+        if self.idx_en and (self.m0 >> 12) & (1 << which):
+            n = n + (self.m0 & 0xff)
+        if not 0 <= n < 256:
+            raise SimError("VGPR index %d out of range" % n)
+        return n
+
+    def _check_ready(self, n):
+        if n in self.pending_regs:
+            raise SimError("v%d read while its load is in flight (missing s_waitcnt)" % n)
+
+    def rv(self, x, which):
+        """Vector source as uint32[64] (VGPR, SGPR broadcast or constant)."""
+        if isinstance(x, str):
+            m = _RE_V.match(x)
+            if m:
+                n = self._vidx(int(m.group(2)), which)
+                self._check_ready(n)
+                val = self.v[n].copy()
+                if m.group(1) == "-":
+                    val ^= np.uint32(0x80000000)
+                return val
+        return np.full(64, self.rs(x), np.uint32)
+
+    def wv(self, x, val, which=3):
+        m = _RE_V.match(x)
+        n = self._vidx(int(m.group(2)), which)
+        if n >= self.nvgpr:
+            raise SimError("write to v%d beyond the %d allocated" % (n, self.nvgpr))
+        self.v[n] = np.asarray(val).astype(np.uint32)
+
+    def vrange(self, x):
+        m = _RE_VR.match(x)
+        if m:
+            return list(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = _RE_V.match(x)
+        return [int(m.group(2))]
+
+    # ---- buffers ------------------------------------------------------------------------------------------------------
+    def _rsrc(self, x):
+        m = _RE_SR.match(x)
+        lo = int(m.group(1))
+        base = self.s[lo] | ((self.s[lo + 1] & 0xffff) << 32)
+        stride = (self.s[lo + 1] >> 16) & 0x3fff
+        if stride != 0:
+            raise SimError("only raw buffers (stride 0) are modelled")
+        return base, self.s[lo + 2]
+
+    def _buf(self, i, store):
+        nreg = {"dword": 1, "dwordx2": 2, "dwordx3": 3, "dwordx4": 4}[i.op.split("_")[-1]]
+        regs = self.vrange(i.args[0])
+        assert len(regs) == nreg
+        voff = self.rv(i.args[1], 0).astype(np.int64) if i.mods.get("offen") else np.zeros(64, np.int64)
+        base, nrec = self._rsrc(i.args[2])
+        soff = self.rs(i.args[3])
+        imm = int(i.mods.get("offset", 0) or 0)
+        if store:
+            for r in regs:
+                self._check_ready(r)
+        for lane in range(64):
+            off = int(voff[lane]) + soff + imm
+            inr = off + 4 * nreg <= nrec
+            for c, r in enumerate(regs):
+                if store:
+                    if inr:
+                        self.mem.write(base + off + 4 * c, self.v[r, lane:lane + 1].view(np.uint8))
+                else:
+                    self.v[r, lane] = self.mem.get(base + off + 4 * c, np.uint32, 1)[0] if inr else 0
+        if not store:
+            for r in regs:
+                if r >= self.nvgpr:
+                    raise SimError("load into v%d beyond the %d allocated" % (r, self.nvgpr))
+            self.pending.append(set(regs))
+            for r in regs:
+                self.pending_regs[r] = self.pending_regs.get(r, 0) + 1
+
+    def _retire(self, keep):
+        while len(self.pending) > keep:
+            for r in self.pending.pop(0):
+                self.pending_regs[r] -= 1
+                if self.pending_regs[r] == 0:
+                    del self.pending_regs[r]
+
+    # ---- run ------------------------------------------------------------------------------------------------------------
+    def run(self, sregs, v0, nvgpr, max_ins=2000000, trace=None):
+        self.reset()
+        self.nvgpr = nvgpr
+        for k, val in sregs.items():
+            self.s[k] = val & MASK32
+        self.v[0] = v0
+        pc = self.labels.get("entry", 0)
+        f32 = lambda a: a.view(np.float32)
+        while True:
+            i = self.ins[pc]
+            pc += 1
+            if i.op == "label":
+                continue
+            self.stats["ins"] += 1
+            if self.stats["ins"] > max_ins:
+                raise SimError("instruction budget exceeded (runaway program?)")
+            if trace is not None:
+                trace.append((pc - 1, i))
+            op, a = i.op, i.args
+            if op.startswith("s_") or op.startswith("pseudo"):
+                self.stats["salu"] += 1
+            if op == "s_endpgm":
+                if self.pending and False:
+                    raise SimError("loads in flight at s_endpgm")
+                return self.stats
+            elif op == "pseudo_div":
+                num, den, skip = a
+                n = self.vrange(num)[0]
+                d = self.vrange(den)[0]
+                self._check_ready(n), self._check_ready(d)
+                with np.errstate(all="ignore"):
+                    self.v[n] = (f32(self.v[n]) / f32(self.v[d])).astype(np.float32).view(np.uint32)
+                self.stats["valu"] += skip
+                k = 0
+                while k < skip:
+                    if self.ins[pc].op != "label":
+                        k += 1
+                    pc += 1
+            elif op in ("s_load_dword", "s_load_dwordx2", "s_load_dwordx4", "s_load_dwordx8", "s_load_dwordx16"):
+                n = {"dword": 1, "dwordx2": 2, "dwordx4": 4, "dwordx8": 8, "dwordx16": 16}[op.split("_")[-1]]
+                addr = self.rs64(a[1]) + (int(a[2]) if isinstance(a[2], int) else self.rs(a[2]))
+                vals = self.mem.get(addr, np.uint32, n)
+                m = _RE_S.match(a[0]) or _RE_SR.match(a[0])
+                lo = int(m.group(1))
+                for k in range(n):
+                    self.s[lo + k] = int(vals[k])
+                self.stats["smem"] += 1
+            elif op == "s_waitcnt":
+                m = re.match(r"vmcnt\((\d+)\)", a[0])
+                if m:
+                    self._retire(int(m.group(1)))
+            elif op == "s_nop":
+                pass
+            elif op == "s_mov_b32":
+                self.ws(a[0], self.rs(a[1]))
+            elif op == "s_movk_i32":
+                self.ws(a[0], int(a[1]))
+            elif op == "s_mov_b64":
+                self.ws64(a[0], self.rs64(a[1]))
+            elif op in ("s_and_b32", "s_or_b32", "s_lshr_b32", "s_lshl_b32"):
+                x, y = self.rs(a[1]), self.rs(a[2])
+                r = {"s_and_b32": x & y, "s_or_b32": x | y, "s_lshr_b32": x >> (y & 31), "s_lshl_b32": (x << (y & 31))}[op] & MASK32
+                self.ws(a[0], r)
+                self.scc = int(r != 0)
+            elif op == "s_mul_i32":
+                self.ws(a[0], (self.rs(a[1]) * self.rs(a[2])) & MASK32)
+            elif op == "s_mul_hi_u32":
+                self.ws(a[0], (self.rs(a[1]) * self.rs(a[2])) >> 32)
+            elif op == "s_add_u32":
+                r = self.rs(a[1]) + self.rs(a[2])
+                self.ws(a[0], r)
+                self.scc = int(r > MASK32)
+            elif op == "s_addc_u32":
+                r = self.rs(a[1]) + self.rs(a[2]) + self.scc
+                self.ws(a[0], r)
+                self.scc = int(r > MASK32)
+            elif op == "s_sub_u32":
+                x, y = self.rs(a[1]), self.rs(a[2])
+                self.ws(a[0], x - y)
+                self.scc = int(y > x)
+            elif op in ("s_min_i32", "s_max_i32"):
+                sx = lambda u: u - (1 << 32) if u & 0x80000000 else u
+                x, y = sx(self.rs(a[1])), sx(self.rs(a[2]))
+                pick0 = x <= y if op == "s_min_i32" else x >= y
+                self.ws(a[0], x if pick0 else y)
+                self.scc = int(pick0)
+            elif op in ("s_cmp_ge_i32", "s_cmp_lt_i32"):
+                sx = lambda u: u - (1 << 32) if u & 0x80000000 else u
+                x, y = sx(self.rs(a[0])), sx(self.rs(a[1]))
+                self.scc = int(x >= y) if op == "s_cmp_ge_i32" else int(x < y)
+            elif op == "s_cmp_lt_u32":
+                self.scc = int(self.rs(a[0]) < self.rs(a[1]))
+            elif op == "s_cmp_ge_u32":
+                self.scc = int(self.rs(a[0]) >= self.rs(a[1]))
+            elif op == "s_cmp_eq_u32":
+                self.scc = int(self.rs(a[0]) == self.rs(a[1]))
+            elif op == "s_cselect_b32":
+                self.ws(a[0], self.rs(a[1]) if self.scc else self.rs(a[2]))
+            elif op == "s_cselect_b64":
+                self.ws64(a[0], self.rs64(a[1]) if self.scc else self.rs64(a[2]))
+            elif op == "s_sext_i32_i16":
+                x = self.rs(a[1]) & 0xffff
+                self.ws(a[0], x - 0x10000 if x & 0x8000 else x)
+            elif op == "s_getpc_b64":
+                self.ws64(a[0], self.code_addr + self.off_of[pc])     # address of the next instruction
+            elif op == "s_setpc_b64":
+                tgt = self.rs64(a[0]) - self.code_addr
+                if tgt not in self.by_off:
+                    raise SimError("s_setpc_b64 to byte offset %d: not an instruction boundary" % tgt)
+                pc = self.by_off[tgt]
+                self.stats["setpc"] += 1
+            elif op == "s_branch":
+                pc = self.labels[a[0]]
+            elif op == "s_cbranch_scc1":
+                if self.scc:
+                    pc = self.labels[a[0]]
+            elif op == "s_cbranch_scc0":
+                if not self.scc:
+                    pc = self.labels[a[0]]
+            elif op == "s_set_gpr_idx_on":
+                self.idx_en = True
+                mode = {"gpr_idx(SRC0)": 1, "gpr_idx(SRC1)": 2, "gpr_idx(SRC2)": 4, "gpr_idx(DST)": 8}[a[1]]
+                self.m0 = (self.m0 & ~0xf0ff) | (self.rs(a[0]) & 0xff) | (mode << 12)
+            elif op == "s_set_gpr_idx_off":
+                self.idx_en = False
+            elif op == "s_set_gpr_idx_idx":
+                self.m0 = (self.m0 & ~0xff) | (self.rs(a[0]) & 0xff)
+            # ---- vector ---------------------------------------------------------------------------------------------------
+            elif op.startswith("buffer_load"):
+                self._buf(i, False)
+                self.stats["vmem"] += 1
+            elif op.startswith("buffer_store"):
+                self._buf(i, True)
+                self.stats["vmem"] += 1
+            else:
+                self.stats["valu"] += 1
+                if op == "v_mov_b32":
+                    self.wv(a[0], self.rv(a[1], 0))
+                elif op == "v_lshlrev_b32":
+                    self.wv(a[0], (self.rv(a[2], 1).astype(np.uint64) << (self.rv(a[1], 0) & 31).astype(np.uint64)) & MASK32)
+                elif op == "v_add_u32":
+                    self.wv(a[0], (self.rv(a[1], 0).astype(np.uint64) + self.rv(a[2], 1)) & MASK32)
+                elif op == "v_mul_u32_u24":
+                    self.wv(a[0], ((self.rv(a[1], 0) & 0xffffff).astype(np.uint64) * (self.rv(a[2], 1) & 0xffffff)) & MASK32)
+                elif op == "v_cmp_gt_u32":
+                    r = self.rv(a[1], 0) > self.rv(a[2], 1)
+                    self.ws64(a[0], int(sum(int(b) << l for l, b in enumerate(r))))
+                elif op == "v_cndmask_b32":
+                    sel = np.array([(self.rs64(a[3]) >> l) & 1 for l in range(64)], bool)
+                    self.wv(a[0], np.where(sel, self.rv(a[2], 1), self.rv(a[1], 0)))
+                elif op == "v_add_f32":
+                    with np.errstate(all="ignore"):
+                        r = f32(self.rv(a[1], 0)) + f32(self.rv(a[2], 1))
+                    self.wv(a[0], r.astype(np.float32).view(np.uint32))
+                elif op == "v_cvt_f32_u32":
+                    self.wv(a[0], self.rv(a[1], 0).astype(np.float32).view(np.uint32))
+                elif op == "v_readlane_b32":
+                    m = _RE_V.match(a[1])
+                    n = self._vidx(int(m.group(2)), 0)
+                    self._check_ready(n)
+                    self.ws(a[0], int(self.v[n, self.rs(a[2]) & 63]))
+                else:
+                    raise SimError("instruction %s is not modelled" % op)

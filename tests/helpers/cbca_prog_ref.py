@@ -1,0 +1,269 @@
+"""Plain-Python statement of the per-patch aggregation programs (csrc/cbca_prog.hip builds them on the GPU, the
+assembly kernel of csrc/asm/cbca_prog_gen.py interprets them) + an op-level interpreter on numpy.
+
+Test infrastructure: `build_program` is the specification the device builder is compared with word for word,
+`run_program` executes a program's LOAD / ADD ops on a pixel-major volume so that a program can be checked against the
+CPU oracle of pf:149-163 without any GPU.
+"""
+import numpy as np
+
+R = 13
+
+
+def arms_of(word):
+    w = int(word)
+    return w & 31, (w >> 5) & 31, (w >> 10) & 31, (w >> 15) & 31     # up, down, left, right
+
+
+def band_rows_of(H, K):
+    per = -(-H // 8)
+    return -(-per // K) * K
+
+
+def prog_stride_dwords(L):
+    """Upper bound of a patch's program: per region row at most ceil(NW / W) + G windows with a LOAD + WAIT each and
+    2 G K arm ops (+ as many again for split arms), one REFILL per 63 ops, END; rounded to whole 64-op chunks."""
+    K, G, W = L["K"], L["G"], L["W"]
+    rows = 2 * K + 2 * R - 1
+    nw = G + 2 * R
+    per_row = 2 * (-(-nw // W) + 2 * G) + 4 * G * K
+    n = rows * per_row + 2
+    n += n // 63 + 1
+    return -(-n // 64) * 64
+
+
+def plan_units(sup0, H, W, y0, x0, L):
+    """The patch's work as a list of window units in execution order: (lo, hi, p_last, runs) - load virtual slots
+    lo .. hi of one region row (p_last = pixel index of slot hi relative to the patch's first region row), then the arm
+    runs (dir, column j, anchor set, first slot, n) that read them."""
+    K, G, WW = L["K"], L["G"], L["W"]
+    MAXD, MAXA = L["MAXD"], L["MAXA"]
+    units = []
+    up, dn, ok = np.zeros((K, G), int), np.zeros((K, G), int), np.zeros((K, G), bool)
+    lowest = highest = y0
+    for k in range(K):
+        y = y0 + k
+        for j in range(G):
+            x = x0 + j
+            if x < W and y < H:
+                u, d, _, _ = arms_of(sup0[y, x])
+                u, d = min(u, y), min(d, H - 1 - y)
+                up[k, j], dn[k, j], ok[k, j] = u, d, True
+                lowest = min(lowest, y - u)
+                highest = max(highest, y + d if d > 0 else y0)
+    nd = y0 + K - 1 - lowest + 1
+    na = highest - y0
+    row0 = max(y0 - R, 0)
+    for t in range(nd + na):
+        yq = y0 + K - 1 - t if t < nd else y0 + 1 + (t - nd)
+        # anchors taking part in this step (pf:155: self, up 1.., then down 1..)
+        aset = np.zeros(G, int)
+        for k in range(K):
+            for j in range(G):
+                if not ok[k, j]:
+                    continue
+                if t < nd:
+                    on = K - 1 - k <= t <= K - 1 - k + up[k, j]
+                else:
+                    on = k <= t - nd <= k + dn[k, j] - 1
+                if on:
+                    aset[j] |= 1 << k
+        cols = [j for j in range(G) if aset[j]]
+        if not cols:
+            continue
+        assert 0 <= yq < H
+        lr = {}
+        for j in cols:
+            _, _, l, r = arms_of(sup0[yq, x0 + j])
+            lr[j] = (min(l, R), min(r, R))
+        c = {j: j + R for j in cols}                                  # virtual slot of the column's own pixel
+
+        def unit(lo, hi, runs):
+            assert 1 <= hi - lo + 1 <= WW
+            p = (yq - row0) * W + (x0 - R + hi)
+            assert 0 <= p < 65536, "pixel index exceeds the op's 16-bit field"
+            units.append((lo, hi, p, runs))
+
+        desc = lambda j, first, n: ("d", j, int(aset[j]), first, n)
+        asc = lambda j, first, n: ("a", j, int(aset[j]), first, n)
+        lo = min(c[j] - lr[j][0] for j in cols)
+        hi = max(c[j] + lr[j][1] for j in cols)
+        if hi - lo + 1 <= WW and max(lr[j][0] + 1 for j in cols) <= MAXD and max(lr[j][1] for j in cols) <= MAXA:
+            unit(lo, hi, [desc(j, c[j], lr[j][0] + 1) for j in cols] + [asc(j, c[j] + 1, lr[j][1]) for j in cols if lr[j][1]])
+            continue
+        # wide row: windows over groups of columns, descending arms first
+        i = 0
+        while i < len(cols):
+            j = cols[i]
+            glo, ghi = c[j] - lr[j][0], c[j]
+            if ghi - glo + 1 > min(WW, MAXD):                          # one arm longer than the window: in pieces
+                first, left = c[j], lr[j][0] + 1
+                while left:
+                    n = min(left, WW, MAXD)
+                    unit(first - n + 1, first, [desc(j, first, n)])
+                    first, left = first - n, left - n
+                i += 1
+                continue
+            grp = [j]
+            while i + len(grp) < len(cols):
+                j2 = cols[i + len(grp)]
+                nlo, nhi = min(glo, c[j2] - lr[j2][0]), max(ghi, c[j2])
+                if nhi - nlo + 1 > WW or lr[j2][0] + 1 > MAXD:
+                    break
+                glo, ghi = nlo, nhi
+                grp.append(j2)
+            unit(glo, ghi, [desc(jj, c[jj], lr[jj][0] + 1) for jj in grp])
+            i += len(grp)
+        acols = [j for j in cols if lr[j][1]]
+        i = 0
+        while i < len(acols):
+            j = acols[i]
+            glo, ghi = c[j] + 1, c[j] + lr[j][1]
+            if ghi - glo + 1 > min(WW, MAXA):
+                first, left = c[j] + 1, lr[j][1]
+                while left:
+                    n = min(left, WW, MAXA)
+                    unit(first, first + n - 1, [asc(j, first, n)])
+                    first, left = first + n, left - n
+                i += 1
+                continue
+            grp = [j]
+            while i + len(grp) < len(acols):
+                j2 = acols[i + len(grp)]
+                nlo, nhi = min(glo, c[j2] + 1), max(ghi, c[j2] + lr[j2][1])
+                if nhi - nlo + 1 > WW or lr[j2][1] > MAXA:
+                    break
+                glo, ghi = nlo, nhi
+                grp.append(j2)
+            unit(glo, ghi, [asc(jj, c[jj] + 1, lr[jj][1]) for jj in grp])
+            i += len(grp)
+    return units
+
+
+def build_program(sup0, H, W, y0, x0, L):
+    """sup0: [H, W] uint32 support words (plane 0).  Returns the uint32 ops of the patch at rows y0.., columns x0...
+    One window (NB = 1): LOAD (which waits), the unit's arms, next unit.  Two windows: the next unit's LOAD is issued
+    before the current unit's arms, WAIT k (k = slots of that newest LOAD) lets exactly the current window arrive."""
+    WW, RS, NB = L["W"], L["RS"], L["NB"]
+    MAXD, MAXA, BLK = L["MAXD"], L["MAXA"], L["BLK"]
+    M0 = L["M0_SRC1"]
+    ops = []
+
+    def emit(op):
+        if len(ops) % 64 == 63:
+            ops.append(L["refill"] | (M0 << 16))
+        ops.append(op & 0xffffffff)
+
+    units = plan_units(sup0, H, W, y0, x0, L)
+
+    def load(i):
+        lo, hi, p, _ = units[i]
+        emit(L["load"][i % NB][hi - lo + 1] | (p << 16))
+
+    def arms(i):
+        lo, hi, p, runs = units[i]
+        wb = (i % NB) * WW                                             # first physical slot of this unit's window
+        for d, j, aset, first, n in runs:
+            nk = bin(aset).count("1")
+            sf = first - lo
+            if d == "d":
+                assert 1 <= n <= MAXD and 0 <= sf - n + 1 and sf < WW
+                emit((L["add"][(j, aset, "d")] + (MAXD - n) * BLK * nk) | ((M0 | (RS * (wb + sf - n + 1))) << 16))
+            else:
+                assert 1 <= n <= MAXA and 0 <= sf and sf + n - 1 < WW
+                emit((L["add"][(j, aset, "a")] + (MAXA - n) * BLK * nk) | ((M0 | (RS * (wb + sf + n - 1))) << 16))
+
+    if NB == 1:
+        for i in range(len(units)):
+            load(i)
+            arms(i)
+    else:
+        if units:
+            load(0)
+        for i in range(len(units)):
+            if i + 1 < len(units):
+                load(i + 1)
+                emit(L["wait"][units[i + 1][1] - units[i + 1][0] + 1] | (M0 << 16))
+            else:
+                emit(L["wait"][0] | (M0 << 16))
+            arms(i)
+    emit(L["end"] | (M0 << 16))
+    return np.array(ops, np.uint32)
+
+
+def build_all(sup0, H, W, L):
+    """[row groups of the 8 bands][column groups][stride] uint32, the layout the kernel indexes."""
+    K, G = L["K"], L["G"]
+    br = band_rows_of(H, K)
+    bg = br // K
+    ngroups = -(-W // G)
+    stride = prog_stride_dwords(L)
+    out = np.zeros((8 * bg, ngroups, stride), np.uint32)
+    longest = 0
+    for rg in range(8 * bg):
+        y0 = rg * K
+        if y0 >= H:
+            continue
+        for cg in range(ngroups):
+            p = build_program(sup0, H, W, y0, cg * G, L)
+            assert len(p) <= stride, (len(p), stride)
+            longest = max(longest, len(p))
+            out[rg, cg, :len(p)] = p
+    return out, dict(band_rows=br, band_groups=bg, ngroups=ngroups, stride=stride, longest=longest)
+
+
+def decode_tables(L):
+    add = {}
+    for (j, aset, d), off in L["add"].items():
+        nk = bin(aset).count("1")
+        maxn = L["MAXD"] if d == "d" else L["MAXA"]
+        for n in range(1, maxn + 1):
+            add[off + (maxn - n) * L["BLK"] * nk] = (j, aset, d, n)
+    load = {off: (b, n) for b, row in enumerate(L["load"]) for n, off in enumerate(row) if n}
+    wait = {off: k for k, off in enumerate(L["wait"])}
+    return add, load, wait
+
+
+def run_program(prog, vol, H, W, y0, x0, L, sup0):
+    """Executes one patch program on vol [H, W, D] (float32); returns {(y, x): quotient vector}."""
+    K, G, WW, VPL = L["K"], L["G"], L["W"], L["RS"]
+    add, load, wait = decode_tables(L)
+    D = vol.shape[2]
+    row0 = max(y0 - R, 0)
+    flat = vol.reshape(H * W, D)
+    win = np.full((WW * L["NB"], D), np.nan, np.float32)
+    acc = np.zeros((K, G, D), np.float32)
+    pc = 0
+    while True:
+        op = int(prog[pc])
+        pc += 1
+        off, par = op & 0xffff, op >> 16
+        if off == L["end"]:
+            break
+        if off == L["refill"]:
+            assert pc % 64 == 0
+            continue
+        if off in wait:
+            continue
+        if off in load:
+            b, n = load[off]
+            win[b * WW:(b + 1) * WW] = np.nan
+            for s in range(n):
+                win[b * WW + s] = flat[row0 * W + par - (n - 1 - s)]
+            continue
+        j, aset, d, n = add[off]
+        idx = (par & 0xff) // VPL
+        assert (par & 0xff) % VPL == 0 and par >> 12 == 2
+        order = [idx + (n - 1) - e for e in range(n)] if d == "d" else [idx - (n - 1) + e for e in range(n)]
+        for s in order:
+            assert 0 <= s < WW * L["NB"] and not np.isnan(win[s]).all(), "window slot %d not loaded" % s
+            for k in range(K):
+                if aset & (1 << k):
+                    acc[k, j] = acc[k, j] + win[s]
+    out = {}
+    for k in range(K):
+        for j in range(G):
+            y, x = y0 + k, x0 + j
+            if y < H and x < W:
+                out[(y, x)] = acc[k, j] / np.float32(int(sup0[y, x]) >> 20)
+    return out

@@ -1,0 +1,162 @@
+"""CPU checks of the program-driven reference-order aggregation (csrc/asm/cbca_prog_gen.py):
+  * the generator's own size model equals what the assembler emits (label offsets = op encodings),
+  * the plain-Python program builder + op-level interpreter reproduce the oracle's pf:149-163 bit for bit,
+  * the generated kernel, executed instruction by instruction by tests/helpers/asm_sim.py on the same programs,
+    reproduces the oracle bit for bit (control flow, relative window addressing, waitcnt discipline, epilogue).
+No GPU, no compute through the product library."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mc-cnn-python_amd", "csrc", "asm"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "helpers"))
+import cbca_prog_gen as gen          # noqa: E402
+import cbca_prog_ref as ref          # noqa: E402
+import asm_sim                       # noqa: E402
+import oracle as o                   # noqa: E402
+import synthetic                     # noqa: E402
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def support_words(img, tau=0.02, Lmax=14):
+    arms, cnt = o.cross_arms(img, tau, Lmax)
+    a = arms.astype(np.uint32)
+    return (a[..., 0] | (a[..., 1] << 5) | (a[..., 2] << 10) | (a[..., 3] << 15) | (cnt.astype(np.uint32) << 20)).astype(np.uint32)
+
+
+def make_case(H, W, D, seed, flat=False):
+    rng = np.random.default_rng(seed)
+    if flat:
+        img = np.zeros((H, W, 1), np.float32)
+    else:
+        img = synthetic.make_pair(H, W, min(D, max(W - 2, 1)), seed=seed)[0]
+    vol = (rng.random((D, H, W), dtype=np.float32) * 3 - 2).astype(np.float32)
+    return img, vol
+
+
+def oracle_cbca(img, vol):
+    out, _ = o.cost_volume_aggregation(img, img, vol, vol, 0.02, 14, 1)
+    return out
+
+
+@pytest.mark.parametrize("vpl,w,nb", [(4, 12, 1), (3, 12, 1), (2, 12, 1), (4, 8, 1), (4, 10, 2)])
+def test_size_model_matches_the_assembler(tmp_path, vpl, w, nb):
+    if not os.path.exists(os.path.join(LLVM, "clang")):
+        pytest.skip("no ROCm assembler")
+    g = gen.Gen(gen.Params(vpl=vpl, W=w, NB=nb)).build()
+    s = tmp_path / "k.s"
+    s.write_text(g.render())
+    obj = tmp_path / "k.o"
+    subprocess.check_call([os.path.join(LLVM, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa",
+                           "-mcpu=gfx950", "-c", str(s), "-o", str(obj)])
+    dis = subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", str(obj)]).decode()
+    off = g.offsets()
+    addr = {}
+    for line in dis.splitlines():
+        if "//" in line and ":" in line.split("//")[1]:
+            a = int(line.split("//")[1].split(":")[0].strip(), 16)
+            addr.setdefault(line.split("//")[0].strip().split()[0], []).append(a)
+    assert addr["s_set_gpr_idx_off"] == [off["end"]]
+    assert addr["s_endpgm"] == [off["done"]]
+    assert addr["s_getpc_b64"][0] + 4 == off["after_getpc"]
+
+
+@pytest.mark.parametrize("H,W,D,seed,flat", [(12, 17, 8, 0, False), (30, 41, 5, 1, False), (9, 33, 4, 2, True),
+                                               (40, 48, 6, 3, False)])
+@pytest.mark.parametrize("w,nb", [(12, 1), (8, 1), (10, 2), (6, 2)])
+def test_programs_reproduce_the_oracle_op_level(H, W, D, seed, flat, w, nb):
+    L = gen.Gen(gen.Params(vpl=4, W=w, NB=nb)).build().layout()
+    img, vol = make_case(H, W, D, seed, flat)
+    sup0 = support_words(img)
+    want = oracle_cbca(img, vol)
+    hwd = np.ascontiguousarray(vol.transpose(1, 2, 0))
+    got = np.full((H, W, D), np.nan, np.float32)
+    for y0 in range(0, H, L["K"]):
+        for x0 in range(0, W, L["G"]):
+            prog = ref.build_program(sup0, H, W, y0, x0, L)
+            assert len(prog) <= ref.prog_stride_dwords(L)
+            for (y, x), q in ref.run_program(prog, hwd, H, W, y0, x0, L, sup0).items():
+                got[y, x] = q
+    assert np.array_equal(got.transpose(2, 0, 1), want)
+
+
+def simulate(g, L, img, vol, code_addr=0x7e00fffff000):
+    """Runs every workgroup of one single-volume launch of the generated kernel in the simulator."""
+    P = g.P
+    D, H, W = vol.shape
+    VPL = P.VPL
+    Dp = -(-D // 4) * 4 if VPL != 3 else -(-D // 3) * 3
+    sup0 = support_words(img)
+    progs, meta = ref.build_all(sup0, H, W, L)
+    hwd = np.zeros((H, W, Dp), np.float32)
+    hwd[:, :, :D] = vol.transpose(1, 2, 0)
+    mem = asm_sim.Memory()
+    a_in = mem.alloc(hwd)
+    a_out = mem.alloc(np.full((H, W, Dp), np.nan, np.float32))
+    a_prog = mem.alloc(progs)
+    a_sup = mem.alloc(np.concatenate([sup0.reshape(-1), np.zeros(64, np.uint32)]))
+    nchunks = -(-Dp // (64 * VPL))
+    karg = np.zeros(0x60 // 4, np.uint32)
+
+    def put64(i, v):
+        karg[i], karg[i + 1] = v & 0xffffffff, v >> 32
+    put64(0, a_in), put64(2, a_in), put64(4, a_out), put64(6, a_out), put64(8, a_prog), put64(10, a_prog)
+    put64(12, a_sup), put64(14, a_sup)
+    karg[16:24] = [Dp, H, W, nchunks, meta["band_rows"], meta["band_groups"], meta["stride"] * 4, meta["ngroups"]]
+    a_k = mem.alloc(karg)
+    wave = asm_sim.Wave(g, mem, code_addr=code_addr)
+    tot = dict(ins=0, valu=0, salu=0, vmem=0, setpc=0)
+    for bx in range(8 * meta["band_groups"]):
+        for by in range(meta["ngroups"]):
+            for bz in range(nchunks):
+                st = wave.run({0: a_k & 0xffffffff, 1: a_k >> 32, 2: bx, 3: by, 4: bz}, np.arange(64, dtype=np.uint32),
+                              P.nvgpr)
+                for k in tot:
+                    tot[k] += st[k]
+    out = mem.get(a_out, np.float32, H * W * Dp).reshape(H, W, Dp)[:, :, :D]
+    return out.transpose(2, 0, 1), tot
+
+
+@pytest.mark.parametrize("vpl,w,nb,H,W,D,seed,flat", [(4, 12, 1, 12, 17, 8, 0, False), (4, 12, 1, 9, 33, 4, 2, True),
+                                                       (3, 12, 1, 14, 23, 6, 4, False), (2, 12, 1, 11, 16, 6, 5, False),
+                                                       (4, 8, 1, 13, 21, 5, 6, True), (4, 12, 1, 7, 12, 300, 7, False),
+                                                       (4, 10, 2, 12, 17, 8, 0, False), (4, 6, 2, 9, 33, 4, 2, True),
+                                                       (3, 10, 2, 14, 23, 6, 4, False)])
+def test_generated_kernel_reproduces_the_oracle_in_the_simulator(vpl, w, nb, H, W, D, seed, flat):
+    g = gen.Gen(gen.Params(vpl=vpl, W=w, NB=nb)).build()
+    L = g.layout()
+    img, vol = make_case(H, W, D, seed, flat)
+    got, st = simulate(g, L, img, vol)
+    want = oracle_cbca(img, vol)
+    assert np.array_equal(got, want, equal_nan=True), "max diff %g" % np.nanmax(np.abs(got - want))
+
+
+def test_generated_kernel_with_scalar_prefetch_in_the_simulator():
+    """The L2 warm-up loads never leave the volume (the simulator faults on any access outside an allocation)."""
+    for (H, W, D, pf) in ((12, 17, 8, 5), (9, 33, 4, 20), (11, 16, 6, 10)):
+        g = gen.Gen(gen.Params(vpl=4, W=12, PF=pf)).build()
+        img, vol = make_case(H, W, D, 3)
+        got, _ = simulate(g, g.layout(), img, vol)
+        assert np.array_equal(got, oracle_cbca(img, vol))
+
+
+def test_simulated_kernel_special_values_and_code_address_carry():
+    """inf / NaN / signed zeros travel through the add chains like through the reference's running sum; the code base
+    sits right below a 4 GiB boundary so that the dispatcher's 64-bit address arithmetic carries."""
+    g = gen.Gen(gen.Params(vpl=4, W=12)).build()
+    L = g.layout()
+    img, vol = make_case(10, 14, 8, 11)
+    vol[1, 3, 4] = np.inf
+    vol[2, 5, 6] = -np.inf
+    vol[3, 7, 8] = np.nan
+    vol[4, :, :] = -0.0
+    got, _ = simulate(g, L, img, vol, code_addr=0x7e00ffffff00)
+    want = oracle_cbca(img, vol)
+    assert np.array_equal(got.view(np.uint32) & 0x7fffffff if False else np.isnan(got), np.isnan(want))
+    m = ~np.isnan(want)
+    assert np.array_equal(got[m].view(np.uint32), want[m].view(np.uint32))

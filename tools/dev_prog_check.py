@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Dev harness (GPU box): launches the assembled program-driven aggregation kernel (csrc/asm/cbca_prog_gen.py) straight
+through the HIP module API with programs built by the plain-Python builder (tests/helpers/cbca_prog_ref.py), checks it
+bit for bit against cbca_hwd_kernel and times both.
+    python tools/dev_prog_check.py [--config cfg2] [--iters 10] [--w 12] [--small-only]"""
+import argparse
+import ctypes
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ("mc-cnn-python_amd/src", "mc-cnn-python_amd/csrc/asm", "tests/helpers", ""):
+    sys.path.insert(0, os.path.join(ROOT, p))
+import numpy as np
+import torch
+import _hipabi as hip
+import stereo_device as sd
+import synthetic
+import cbca_prog_gen as gen
+import cbca_prog_ref as ref
+from bench import CONFIGS
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def build_hsaco(vpl, w, outdir, nb=1, debug=0, pf=0):
+    os.makedirs(outdir, exist_ok=True)
+    g = gen.Gen(gen.Params(vpl=vpl, W=w, NB=nb, debug=debug, PF=pf)).build()
+    base = os.path.join(outdir, "cbca_prog_v%d_w%d_b%d_g%d_p%d" % (vpl, w, nb, debug, pf))
+    if not os.path.exists(base + ".hsaco") or os.path.getmtime(base + ".hsaco") < os.path.getmtime(gen.__file__):
+        open(base + ".s", "w").write(g.render())
+        subprocess.check_call([LLVM + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c",
+                               base + ".s", "-o", base + ".o"])
+        subprocess.check_call([LLVM + "/ld.lld", "-shared", base + ".o", "-o", base + ".hsaco"])
+    return g, base + ".hsaco"
+
+
+class Module:
+    def __init__(self, path, name):
+        self.hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        self.mod = ctypes.c_void_p()
+        rc = self.hip.hipModuleLoad(ctypes.byref(self.mod), path.encode())
+        assert rc == 0, "hipModuleLoad -> %d" % rc
+        self.fn = ctypes.c_void_p()
+        rc = self.hip.hipModuleGetFunction(ctypes.byref(self.fn), self.mod, name.encode())
+        assert rc == 0, "hipModuleGetFunction -> %d" % rc
+
+    def launch(self, grid, karg_bytes, lds=0):
+        buf = ctypes.create_string_buffer(karg_bytes, len(karg_bytes))
+        size = ctypes.c_size_t(len(karg_bytes))
+        extra = (ctypes.c_void_p * 5)(1, ctypes.cast(buf, ctypes.c_void_p).value, 2,
+                                       ctypes.cast(ctypes.pointer(size), ctypes.c_void_p).value, 3)
+        rc = self.hip.hipModuleLaunchKernel(self.fn, grid[0], grid[1], grid[2], 64, 1, 1, lds,
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), None, extra)
+        assert rc == 0, "hipModuleLaunchKernel -> %d" % rc
+
+
+def kargs(ins, outs, progs, sups, Dp, H, W, nchunks, meta):
+    k = np.zeros(0x60 // 4, np.uint32)
+    for i, t in enumerate(ins + outs + progs + sups):
+        a = t.data_ptr()
+        k[2 * i], k[2 * i + 1] = a & 0xffffffff, a >> 32
+    k[16:24] = [Dp, H, W, nchunks, meta["band_rows"], meta["band_groups"], meta["stride"] * 4, meta["ngroups"]]
+    return k.tobytes()
+
+
+def timeit(fn, iters):
+    fn(); torch.cuda.synchronize()
+    a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def programs_for(sup, H, W, L):
+    sup0 = sup.cpu().numpy().view(np.uint32).reshape(H, W)
+    t = time.time()
+    progs, meta = ref.build_all(sup0, H, W, L)
+    meta["build_s"] = time.time() - t
+    return torch.from_numpy(progs.view(np.int32)).cuda(), meta
+
+
+def check_shape(mod, g, L, H, W, D, seed, flat=False):
+    P = g.P
+    if flat:
+        img = torch.zeros((H, W), device="cuda")
+    else:
+        Li = synthetic.make_pair(H, W, min(D, W - 2), seed=seed)[0]
+        img = torch.from_numpy(Li[:, :, 0]).cuda()
+    sup = sd.cross_arms(img, 0.02, 14)
+    Dp = sd.hwd_pitch(D)
+    gt = torch.Generator(device="cuda").manual_seed(seed)
+    a = (torch.rand((H, W, Dp), device="cuda", generator=gt) * 3 - 2).contiguous()
+    want, _ = sd.cbca_hwd(a, torch.full_like(a, float("nan")), sup, D, 1, 14)
+    progs, meta = programs_for(sup, H, W, L)
+    out = torch.full_like(a, float("nan"))
+    nchunks = -(-Dp // (64 * P.VPL))
+    mod.launch((8 * meta["band_groups"], meta["ngroups"], nchunks),
+               kargs([a, a], [out, out], [progs, progs], [sup, sup], Dp, H, W, nchunks, meta))
+    torch.cuda.synchronize()
+    ok = torch.equal(out[:, :, :D].nan_to_num(777.), want[:, :, :D].nan_to_num(777.))
+    print("shape %dx%dx%d seed %d flat %d: %s  (longest program %d of %d)" % (H, W, D, seed, flat, ok, meta["longest"],
+                                                                             meta["stride"]), flush=True)
+    if not ok:
+        d = (out[:, :, :D] != want[:, :, :D])
+        idx = d.nonzero()[:5].tolist()
+        print("   first mismatches (y,x,d):", idx, [float(out[tuple(i)]) for i in idx], [float(want[tuple(i)]) for i in idx])
+    return ok
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="cfg2"); ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--w", type=int, default=12); ap.add_argument("--small-only", action="store_true")
+    ap.add_argument("--nb", type=int, default=1); ap.add_argument("--skip-small", action="store_true")
+    ap.add_argument("--experiments", action="store_true"); ap.add_argument("--pf", default="")
+    args = ap.parse_args()
+    hip.require_device()
+    allok = True
+    for vpl in (() if args.skip_small else (4, 2, 3)):
+        g, path = build_hsaco(vpl, args.w, os.path.join(ROOT, "mc-cnn-python_amd", "build", "asm"), args.nb)
+        mod = Module(path, g.P.name())
+        L = g.layout()
+        shapes = {4: [(24, 32, 8, 0), (37, 61, 200, 2), (20, 300, 256, 6), (30, 47, 400, 7), (64, 130, 250, 3)],
+                  2: [(40, 48, 16, 1), (50, 70, 2, 4), (33, 45, 128, 5)], 3: [(28, 66, 192, 8), (31, 50, 96, 9)]}[vpl]
+        for (H, W, D, seed) in shapes:
+            assert sd.hwd_pitch(D) % vpl == 0
+            allok &= check_shape(mod, g, L, H, W, D, seed)
+        if vpl == 4:
+            allok &= check_shape(mod, g, L, 60, 80, 20, 0, flat=True)
+    print("ALL OK" if allok else "MISMATCH", flush=True)
+    if args.small_only:
+        sys.exit(0 if allok else 1)
+    H, W, D = CONFIGS[args.config]
+    Dp = sd.hwd_pitch(D)
+    vpl = 2 if Dp <= 128 else 3 if (Dp <= 192 and Dp % 3 == 0) else 4
+    g, path = build_hsaco(vpl, args.w, os.path.join(ROOT, "mc-cnn-python_amd", "build", "asm"), args.nb)
+    mod = Module(path, g.P.name()); L = g.layout()
+    Li, Ri, _, _, _ = synthetic.make_pair(H, W, D, seed=100)
+    dl, dr = torch.from_numpy(Li[:, :, 0]).cuda(), torch.from_numpy(Ri[:, :, 0]).cuda()
+    sl, sr = sd.cross_arms_pair(dl, dr, 0.02, 14)
+    pl, meta = programs_for(sl, H, W, L)
+    pr, meta_r = programs_for(sr, H, W, L)
+    print("program build (python): %.1f s + %.1f s; longest %d / %d of stride %d dwords" % (
+        meta["build_s"], meta_r["build_s"], meta["longest"], meta_r["longest"], meta["stride"]), flush=True)
+    used = int((pl.view(-1, meta["stride"]) != 0).sum()) * 4
+    print("program bytes used (left image): %.1f MB" % (used / 1e6))
+    gt = torch.Generator(device="cuda").manual_seed(0)
+    a = -torch.rand((H, W, Dp), device="cuda", generator=gt); b = torch.empty_like(a)
+    c = a.clone(); d = torch.empty_like(a)
+    nchunks = -(-Dp // (64 * vpl))
+    want_l, _ = sd.cbca_hwd(a, torch.empty_like(a), sl, D, 1, 14)
+    want_l = want_l.clone()
+    want_r, _ = sd.cbca_hwd(c, torch.empty_like(c), sr, D, 1, 14)
+    want_r = want_r.clone()
+    ka = kargs([a, c], [b, d], [pl, pr], [sl, sr], Dp, H, W, nchunks, meta)
+    b.fill_(float("nan")); d.fill_(float("nan"))
+    mod.launch((8 * meta["band_groups"], meta["ngroups"], nchunks * 2), ka)
+    torch.cuda.synchronize()
+    print("full size bit-exact vs cbca_hwd: left %s right %s" % (torch.equal(b, want_l), torch.equal(d, want_r)), flush=True)
+    vb = 4.0 * H * W * D
+    ms = timeit(lambda: mod.launch((8 * meta["band_groups"], meta["ngroups"], nchunks * 2), ka), args.iters)
+    print("W=%d NB=%d regs=%d" % (args.w, args.nb, g.P.nvgpr))
+    print("cbca_prog pair      %8.4f ms  %6.1f GB/s (%.1f%% of 8 TB/s)" % (ms, 4 * vb / ms / 1e6, 4 * vb / ms / 1e6 / 80), flush=True)
+    for pf in [int(x) for x in args.pf.split(",") if x]:
+        g2, path2 = build_hsaco(vpl, args.w, os.path.join(ROOT, "mc-cnn-python_amd", "build", "asm"), args.nb, 0, pf)
+        m2 = Module(path2, g2.P.name())
+        b.fill_(float("nan")); d.fill_(float("nan"))
+        m2.launch((8 * meta["band_groups"], meta["ngroups"], nchunks * 2), ka)
+        torch.cuda.synchronize()
+        ok = torch.equal(b, want_l) and torch.equal(d, want_r)
+        ms = timeit(lambda: m2.launch((8 * meta["band_groups"], meta["ngroups"], nchunks * 2), ka), args.iters)
+        print("  scalar prefetch %2d columns ahead: %8.4f ms  bit-exact %s" % (pf, ms, ok), flush=True)
+    if args.experiments:
+        grid = (8 * meta["band_groups"], meta["ngroups"], nchunks * 2)
+        for lds in (20480, 40960, 81920):
+            ms = timeit(lambda: mod.launch(grid, ka, lds), args.iters)
+            print("  with %d B of LDS per wave (%d waves per SIMD at most): %8.4f ms" % (lds, 163840 // lds // 4, ms), flush=True)
+        # timing only (wrong results): ops replaced by WAIT 0 / kernels without division or stores
+        loads = set(x for row in L["load"] for x in row[1:])
+        special = loads | set(L["wait"]) | {L["end"], L["refill"]}
+        nop = L["wait"][0] | (L["M0_SRC1"] << 16)
+
+        def variant(fl, fa, m=None, note=""):
+            ps = []
+            for pt in (pl, pr):
+                pn = pt.cpu().numpy().view(np.uint32).copy()
+                off = pn & 0xffff
+                isload = np.isin(off, list(loads))
+                isadd = (pn != 0) & ~np.isin(off, list(special))
+                rng = np.random.default_rng(0)
+                pn[isload & (rng.random(pn.shape) < fl)] = nop
+                pn[isadd & (rng.random(pn.shape) < fa)] = nop
+                ps.append(torch.from_numpy(pn.view(np.int32)).cuda())
+            k2 = kargs([a, c], [b, d], ps, [sl, sr], Dp, H, W, nchunks, meta)
+            ms = timeit(lambda: (m or mod).launch(grid, k2), args.iters)
+            print("  LOAD ops dropped %3.0f%%, ADD ops dropped %3.0f%% %s: %8.4f ms" % (100 * fl, 100 * fa, note, ms), flush=True)
+        variant(0.5, 0)
+        variant(1.0, 0)
+        variant(1.0, 1.0)
+        variant(0.0, 1.0)
+        for dbg, note in ((1, "no division"), (2, "no stores"), (3, "no division, no stores")):
+            g2, path2 = build_hsaco(vpl, args.w, os.path.join(ROOT, "mc-cnn-python_amd", "build", "asm"), args.nb, dbg)
+            m2 = Module(path2, g2.P.name())
+            variant(0.0, 0.0, m2, note)
+            variant(1.0, 0.0, m2, note)
+            variant(1.0, 1.0, m2, note)
+    ms = timeit(lambda: sd.cbca_hwd_pair(a, b, sl, c, d, sr, D, 1, 14), args.iters)
+    print("cbca_iter_hwd_pair  %8.4f ms  %6.1f GB/s (%.1f%% of 8 TB/s)" % (ms, 4 * vb / ms / 1e6, 4 * vb / ms / 1e6 / 80), flush=True)
+    sys.exit(0 if allok else 1)
+
+
+if __name__ == "__main__":
+    main()
