@@ -45,7 +45,7 @@ extern "C" {
 
 typedef void *mccnn_stream_t; /* hipStream_t */
 
-#define MCCNN_ABI_VERSION 1
+#define MCCNN_ABI_VERSION 2 /* 2: support buffer grew by the window-mask plane (22 B / pixel), *_hwd entry points */
 
 #define MCCNN_E_INVALID (-1)     /* bad argument (null pointer, non-positive size, unsupported shape) */
 #define MCCNN_E_UNSUPPORTED (-2) /* shape outside what the kernels were built for (e.g. D > 512 for SGM) */
@@ -145,8 +145,10 @@ int mccnn_cbca_iter_both(const float *in, float *out, const mccnn_support_t *sup
  * list of p (vertical arm self,up..,down.. x horizontal arm self,left..,right..) divided by count[p].  A wave owns a
  * few neighbouring pixels and all their disparities (disparities on lanes), so the region walk runs on the scalar
  * unit and every region element is one coalesced load: same bits as mccnn_cbca_iter(..., MCCNN_CBCA_REFERENCE_ORDER)
- * on the plane-major volume, an order of magnitude faster.  Only plane 0 of the support buffer is read (up to 28
- * bytes past its last word, inside the buffer mccnn_support_bytes sizes).  L <= 14 (arms <= 13); in != out.
+ * on the plane-major volume, an order of magnitude faster.  The kernel reads plane 0 of the support buffer AND its
+ * window-mask plane (one word per pixel, behind the derived planes): `support` must be the start of the WHOLE
+ * mccnn_support_bytes(H, W) buffer that mccnn_cross_arms wrote - a copy of plane 0 alone is refused
+ * (MCCNN_E_INVALID: the *_hwd entry points only accept pointers mccnn_cross_arms has written).  L <= 14; in != out.
  * The _pair form takes the left and the right volume in one launch (pf:116-180 loops over the two views). */
 int mccnn_cbca_iter_hwd(const float *in_hwd, float *out_hwd, const mccnn_support_t *support, int D, int H, int W, int L,
                         mccnn_stream_t stream);

@@ -576,7 +576,7 @@ extern "C" int mccnn_cbca_iter_hwd(const float *in_hwd, float *out_hwd, const mc
     MCCNN_REQUIRE(D > 0 && H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_cbca_iter_hwd: non-positive size");
     MCCNN_REQUIRE(L >= 1 && L <= 14, MCCNN_E_UNSUPPORTED,
                   "mccnn_cbca_iter_hwd: L=%d outside [1,14] (use mccnn_cbca_iter on the plane-major volume)", L);
-    if (const int rc = check_support_record(support, H, W, L, "mccnn_cbca_iter_hwd")) return rc;
+    if (const int rc = check_support_record(support, H, W, L, "mccnn_cbca_iter_hwd", true)) return rc;
     const hw::Jobs jobs = {{in_hwd, nullptr}, {out_hwd, nullptr}, {support, nullptr}, 1, {nullptr, nullptr}, {1, 1}, D};
     return hw::launch(jobs, D, H, W, (hipStream_t)stream);
 }
@@ -593,9 +593,9 @@ extern "C" int mccnn_cbca_iter_hwd_pair(const float *in_left, float *out_left, c
                   MCCNN_E_INVALID, "mccnn_cbca_iter_hwd_pair: outputs must not alias an input or each other");
     MCCNN_REQUIRE(D > 0 && H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_cbca_iter_hwd_pair: non-positive size");
     MCCNN_REQUIRE(L >= 1 && L <= 14, MCCNN_E_UNSUPPORTED, "mccnn_cbca_iter_hwd_pair: L=%d outside [1,14]", L);
-    int rc = check_support_record(support_left, H, W, L, "mccnn_cbca_iter_hwd_pair");
+    int rc = check_support_record(support_left, H, W, L, "mccnn_cbca_iter_hwd_pair", true);
     if (rc) return rc;
-    rc = check_support_record(support_right, H, W, L, "mccnn_cbca_iter_hwd_pair");
+    rc = check_support_record(support_right, H, W, L, "mccnn_cbca_iter_hwd_pair", true);
     if (rc) return rc;
     const hw::Jobs jobs = {{in_left, in_right}, {out_left, out_right}, {support_left, support_right}, 2,
                            {nullptr, nullptr}, {1, 1}, D};
@@ -616,9 +616,9 @@ extern "C" int mccnn_cbca_iter_hwd_pair_wta(const float *in_left, float *out_lef
                   MCCNN_E_INVALID, "mccnn_cbca_iter_hwd_pair_wta: outputs must not alias an input or each other");
     MCCNN_REQUIRE(D > 0 && H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_cbca_iter_hwd_pair_wta: non-positive size");
     MCCNN_REQUIRE(L >= 1 && L <= 14, MCCNN_E_UNSUPPORTED, "mccnn_cbca_iter_hwd_pair_wta: L=%d outside [1,14]", L);
-    int rc = check_support_record(support_left, H, W, L, "mccnn_cbca_iter_hwd_pair_wta");
+    int rc = check_support_record(support_left, H, W, L, "mccnn_cbca_iter_hwd_pair_wta", true);
     if (rc) return rc;
-    rc = check_support_record(support_right, H, W, L, "mccnn_cbca_iter_hwd_pair_wta");
+    rc = check_support_record(support_right, H, W, L, "mccnn_cbca_iter_hwd_pair_wta", true);
     if (rc) return rc;
     // a volume that is not stored still needs a valid (never dereferenced) base for its empty descriptors
     const hw::Jobs jobs = {{in_left, in_right}, {out_left, store_right ? out_right : out_left},

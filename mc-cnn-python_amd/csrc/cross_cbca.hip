@@ -900,10 +900,13 @@ std::mutex g_support_mu;
 std::unordered_map<const void *, SupportInfo> g_support;
 }  // namespace
 
-int mccnn::check_support_record(const mccnn_support_t *support, int H, int W, int L, const char *who)
+int mccnn::check_support_record(const mccnn_support_t *support, int H, int W, int L, const char *who, bool must_be_known)
 {
     std::lock_guard<std::mutex> lock(g_support_mu);
     const auto it = g_support.find(support);
+    MCCNN_REQUIRE(!must_be_known || it != g_support.end(), MCCNN_E_INVALID,
+                  "%s: `support` is not a buffer mccnn_cross_arms has written (the kernel also reads the planes behind "
+                  "plane 0: pass the whole mccnn_support_bytes(H, W) buffer, not a copy of its first plane)", who);
     if (it != g_support.end()) {
         MCCNN_REQUIRE(it->second.H == H && it->second.W == W, MCCNN_E_INVALID,
                       "%s: support plane was built for a %dx%d image, volume is %dx%d", who, it->second.W, it->second.H,

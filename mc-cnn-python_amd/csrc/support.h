@@ -61,7 +61,8 @@ __host__ __device__ __forceinline__ size_t wmask_plane_bytes(int H, int W)
 }
 
 // Host-side record of what mccnn_cross_arms last wrote where (cross_cbca.hip): refuses a support plane built for
-// another image size or with longer arms than the caller states; unknown pointers pass.
-int check_support_record(const mccnn_support_t *support, int H, int W, int L, const char *who);
+// another image size or with longer arms than the caller states; unknown pointers pass unless must_be_known (the
+// pixel-major kernels read planes behind plane 0, which only a buffer written by mccnn_cross_arms has).
+int check_support_record(const mccnn_support_t *support, int H, int W, int L, const char *who, bool must_be_known = false);
 
 }  // namespace mccnn

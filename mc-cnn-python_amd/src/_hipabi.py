@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MCCNN_HIP_LIB selects another build of the same library (kernel A/B measurements); there is still no CPU path.
 LIB_PATH = os.environ.get("MCCNN_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libmccnn_hip.so")
 
+MCCNN_ABI_VERSION = 2      # include/mccnn.h; load() refuses a library built from another header
 MCCNN_CV_EXACT = 0
 MCCNN_CV_MFMA = 1
 MCCNN_CBCA_SEPARABLE = 0
@@ -91,6 +92,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the ABI and this table ever diverge
         fn.restype = res
         fn.argtypes = args
+    have = lib.mccnn_version()
+    if have != MCCNN_ABI_VERSION:
+        raise MccnnHipError("%s implements ABI version %d, this binding expects %d: rebuild the library "
+                            "(`make -C mc-cnn-python_amd`)" % (LIB_PATH, have, MCCNN_ABI_VERSION))
     _lib = lib
     return lib
 

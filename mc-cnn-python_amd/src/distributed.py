@@ -61,6 +61,15 @@ def gather_elapsed(elapsed_seconds, device=None):
     return [float(x.item()) for x in out]
 
 
+def gather_objects(obj):
+    """all_gather of one small picklable object per rank (which device every rank drives, for the bench line)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
 def aggregate_throughput(units_per_rank, elapsed_per_rank):
     """Whole-job rate: everything all ranks processed over the slowest rank's time."""
     return float(sum(units_per_rank)) / max(elapsed_per_rank)

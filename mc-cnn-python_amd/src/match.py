@@ -25,11 +25,13 @@ from datetime import datetime
 
 import numpy as np
 
+import util
+
 # Flag names, types and defaults are the reference's command line (match.py:15-43) - that is the drop-in contract;
 # the help texts are this project's.
 parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter,
                                  description="MC-CNN stereo matching of a list of Middlebury-style pairs on one MI355X")
-parser.add_argument("-g", "--gpu", type=str, default="0",
+parser.add_argument("-g", "--gpu", type=str, default="0", action=util.ExplicitStore,
                     help="index of the GPU this process uses (when not given, a HIP_VISIBLE_DEVICES already in the "
                          "environment stands; ignored under torchrun: one rank per GPU)")
 parser.add_argument("-ps", "--patch_size", type=int, default=11,
@@ -108,13 +110,6 @@ def hyper_parameters(args):
                 sgm_V=args.sgm_V, blur_sigma=args.blur_sigma, blur_threshold=args.blur_threshold)
 
 
-def _gpu_flag_given(argv):
-    import sys
-    words = sys.argv[1:] if argv is None else list(argv)
-    return any(w in ("-g", "--gpu") or w.startswith("--gpu=") or (w.startswith("-g") and len(w) > 2 and w[2] != "-")
-               for w in words)
-
-
 def main(argv=None):
     args = parser.parse_args(argv)
     if args.fast and args.exact:
@@ -123,12 +118,7 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and (_gpu_flag_given(argv) or "HIP_VISIBLE_DEVICES" not in os.environ):
-        # the reference pins the process to the requested card through the environment (match.py:59); ROCm reads
-        # HIP_VISIBLE_DEVICES, torch also honours CUDA_VISIBLE_DEVICES - both are set to the same value.  Without an
-        # explicit -g a scheduler's own HIP_VISIBLE_DEVICES stands (the default "0" only fills an empty environment).
-        os.environ["HIP_VISIBLE_DEVICES"] = args.gpu
-        os.environ["CUDA_VISIBLE_DEVICES"] = args.gpu
+    util.pin_gpu(args, world)     # before torch initialises HIP
 
     import torch
     import _hipabi as hip

@@ -545,7 +545,9 @@ class StereoMatcher(object):
 
     net: model.NET with weights loaded (kept resident; the reference re-restores per pair, pf:43).
     cv_mode / cbca_order select the bit-exact (default, like process_functional and match.py) or the fast,
-    tolerance-bounded variant of those two stages.
+    tolerance-bounded variant of those two stages.  NOTE (round 3 on): the defaults are the bit-exact variants
+    (MCCNN_CV_EXACT, MCCNN_CBCA_REFERENCE_ORDER: 13.7 ms per Middlebury-half pair); callers that relied on the
+    earlier default (the fast variants, 9.3 ms) must ask for MCCNN_CV_MFMA / MCCNN_CBCA_SEPARABLE explicitly.
     """
 
     def __init__(self, net, hp=None, cv_mode=hip.MCCNN_CV_EXACT, cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER,
@@ -609,10 +611,12 @@ class StereoMatcher(object):
                 and not self.extras["both_view_support"]
                 and int(self.hp["cbca_distance"]) <= 14)
 
-    def match(self, left_image, right_image, ndisp, timer=_NO_TIMER, keep=None, _static_out=False):
+    def match(self, left_image, right_image, ndisp, timer=_NO_TIMER, keep=None, _static_out=False, out=None):
         """left/right: standardised float32 device tensors [H,W] (or [H,W,1]).  Returns the final left disparity
-        map [H,W] on the device (a fresh tensor; the matcher's workspace is reused by the next call).  `keep`, if a
-        dict, receives intermediate device tensors in the reference's [D,H,W] layout (tests)."""
+        map [H,W] on the device.  The matcher's workspace is reused by the next call, so the map is handed out as a
+        copy - one [H,W] allocation + one copy per pair; pass `out` (a contiguous float32 [H,W] device tensor) and the
+        last kernel writes there instead: nothing is allocated but the conv activations.  `keep`, if a dict, receives
+        intermediate device tensors in the reference's [D,H,W] layout (tests)."""
         hp = self.hp
         L = left_image.reshape(left_image.shape[0], left_image.shape[1]).contiguous()
         R = right_image.reshape(right_image.shape[0], right_image.shape[1]).contiguous()
@@ -735,22 +739,25 @@ class StereoMatcher(object):
             timer.stop()
             sub = lambda di: subpixel(di, lcv, out=m[3], numpy1_promotion=ex["numpy1_promotion"])   # noqa: E731
 
-        # per-pair maps live in the workspace unless the caller keeps intermediates (tests): a pair then allocates
-        # nothing but the conv activations and never blocks the host
+        # per-pair maps live in the workspace unless the caller keeps intermediates (tests): apart from the returned
+        # map (see `out`) a pair then allocates nothing but the conv activations and never blocks the host
         timer.start("post")
         st = lr_status(dl, dr, D, out=ws["status"] if keep is None else None)
         di = interpolate(dl, st, out=m[2], directions=ex["interpolation_directions"],
                          occlusion_from_left=ex["occlusion_from_left"])
         ds = sub(di)
         dm = median(ds, 5, 5, out=m[4])
-        db = bilateral(L, dm, 5, 5, 0, hp["blur_sigma"], hp["blur_threshold"], out=m[5])
+        if out is not None and (tuple(out.shape) != (H, W) or out.dtype != torch.float32 or not out.is_contiguous()
+                                or out.device != L.device):
+            raise ValueError("match: `out` must be a contiguous float32 [H,W] tensor on the images' device")
+        db = bilateral(L, dm, 5, 5, 0, hp["blur_sigma"], hp["blur_threshold"], out=out if out is not None else m[5])
         timer.stop()
         if keep is not None:
             keep.update(wta=(dl, dr), status=st, interp=di, subpixel=ds, median=dm, bilateral=db)
             return db
-        # the workspace map is overwritten by the next pair: hand out a copy unless the caller (match_graph) wants
-        # the static buffer
-        return db if _static_out else db.clone()
+        # the workspace map is overwritten by the next pair: hand out a copy unless the caller passed its own tensor
+        # or (match_graph) wants the static buffer
+        return db if (_static_out or out is not None) else db.clone()
 
     def match_graph(self, left_image, right_image, ndisp):
         """match() replayed as ONE hipGraph launch: the ~75 kernel launches of a pair are captured once per image

@@ -28,9 +28,11 @@ from datetime import datetime
 
 import numpy as np
 
+import util
+
 parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter,
                                  description="training of the MC-CNN matching network (fast architecture)")
-parser.add_argument("-g", "--gpu", type=str, default="0",
+parser.add_argument("-g", "--gpu", type=str, default="0", action=util.ExplicitStore,
                     help="index of the GPU to train on (when not given, a HIP_VISIBLE_DEVICES already in the environment "
                          "stands; ignored under torchrun)")
 parser.add_argument("-ps", "--patch_size", type=int, default=11, help="side of the square training patches")
@@ -136,12 +138,7 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    import sys
-    words = sys.argv[1:] if argv is None else list(argv)
-    explicit = any(w in ("-g", "--gpu") or w.startswith("--gpu=") for w in words)
-    if world == 1 and (explicit or "HIP_VISIBLE_DEVICES" not in os.environ):
-        os.environ["HIP_VISIBLE_DEVICES"] = args.gpu   # an explicit -g pins the card (train.py:57); otherwise a
-        os.environ["CUDA_VISIBLE_DEVICES"] = args.gpu  # scheduler's HIP_VISIBLE_DEVICES stands
+    util.pin_gpu(args, world)     # an explicit -g pins the card (train.py:57), before torch initialises HIP
 
     import torch
     import distributed as mgpu

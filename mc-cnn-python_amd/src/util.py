@@ -9,6 +9,7 @@ match.py needs around the timed region.  Image decode / PGM encode live in OpenC
   * saveDisparity() writes the saturate-cast (round-half-even, clamp 0..255) uint8 map as binary PGM, which is what
     cv2.imwrite does with a float32 matrix.
 """
+import argparse
 import os
 import struct
 
@@ -113,3 +114,23 @@ def read_gray(path):
     # this image, so its own share (the call above) stays unpinned.
     gray = (rgb[:, :, 0] * 9797 + rgb[:, :, 1] * 19234 + rgb[:, :, 2] * 3737) >> 15
     return gray.astype(np.uint8)
+
+
+class ExplicitStore(argparse.Action):
+    """argparse action for `-g/--gpu`: stores the value like the default action and records that the flag was GIVEN
+    (`<dest>_explicit`), whatever its spelling (-g 1, -g1, --gpu=1, an abbreviation such as --gp 1).  match.py and
+    train.py pin the process to that card through HIP_VISIBLE_DEVICES only then - or when the environment is empty."""
+
+    def __call__(self, parser, namespace, values, option_string=None):
+        setattr(namespace, self.dest, values)
+        setattr(namespace, self.dest + "_explicit", True)
+
+
+def pin_gpu(args, world):
+    """The reference pins the process to the requested card through the environment (match.py:59, train.py:57); ROCm
+    reads HIP_VISIBLE_DEVICES, torch also honours CUDA_VISIBLE_DEVICES.  An explicit -g always wins; without one a
+    scheduler's own HIP_VISIBLE_DEVICES stands (the default "0" only fills an empty environment); under torchrun
+    (world > 1: one rank per GPU) -g is ignored."""
+    if world == 1 and (getattr(args, "gpu_explicit", False) or "HIP_VISIBLE_DEVICES" not in os.environ):
+        os.environ["HIP_VISIBLE_DEVICES"] = args.gpu
+        os.environ["CUDA_VISIBLE_DEVICES"] = args.gpu

@@ -1,7 +1,7 @@
 """CPU checks of the program-driven reference-order aggregation (csrc/asm/cbca_prog_gen.py):
   * the generator's own size model equals what the assembler emits (label offsets = op encodings),
   * the plain-Python program builder + op-level interpreter reproduce the oracle's pf:149-163 bit for bit,
-  * the generated kernel, executed instruction by instruction by tests/helpers/asm_sim.py on the same programs,
+  * the generated kernel, executed instruction by instruction by tests/asmtools/asm_sim.py on the same programs,
     reproduces the oracle bit for bit (control flow, relative window addressing, waitcnt discipline, epilogue).
 No GPU, no compute through the product library."""
 import os
@@ -13,7 +13,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mc-cnn-python_amd", "csrc", "asm"))
-sys.path.insert(0, os.path.join(ROOT, "tests", "helpers"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "asmtools"))
 import cbca_prog_gen as gen          # noqa: E402
 import cbca_prog_ref as ref          # noqa: E402
 import asm_sim                       # noqa: E402

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN_DIR, ROOT
+import tolerances as tol
 
 pytestmark = pytest.mark.gpu
 
@@ -26,7 +27,7 @@ def _write_pair(dirname, H, W, ndisp, seed):
                 "width=%d\nheight=%d\nndisp=%d\nisint=0\nvmin=0\nvmax=%d\ndyavg=0\ndymax=0\n" % (W, H, ndisp, ndisp))
 
 
-@pytest.mark.parametrize("extra,threshold", [([], 0.999), (["--features", "split_f16"], 0.985)],
+@pytest.mark.parametrize("extra,threshold", [([], 0.999), (["--features", "split_f16"], tol.FAST_FRAC_WITHIN_1E3_PX)],
                          ids=["default_bit_exact", "bit_exact_stages_behind_split_features"])
 def test_match_cli_writes_reference_outputs(tmp_path, net_layers, extra, threshold):
     import oracle as o
@@ -81,6 +82,8 @@ def test_bench_two_ranks_share_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["unit"] == "Mdisparities/s" and d["cpu_baseline"] is None
+    assert [x["rank"] for x in d["per_rank_device"]] == [0, 1] and d["process_group"] == "gloo x2"
+    assert d["dtype"] == "f32" and d["parity"]["final_map_bit_identical"] and d["parity_violations"] == []
     # value = 2 ranks x 256*256*64 voxels x 3 steps / (max-rank seconds): consistent with ms_per_step
     want = 2 * 256 * 256 * 64 * 1e-6 / (d["ms_per_step"] * 1e-3)
     assert abs(d["value"] - want) <= 0.02 * want
@@ -116,7 +119,24 @@ def test_bench_bit_exact_stages_behind_split_features():
     assert d["roofline"]["kernel"] == "cbca_iter_hwd_pair" and "split-operand" in d["config"]["features"]
     assert d["parity"]["timed_path_equals_kernel_by_kernel"] and d["parity"]["against"].startswith("bit-exact variant (library")
     assert d["parity"]["wta_flips_left"] + d["parity"]["wta_flips_right"] <= 4
-    assert d["parity"]["frac_within_1e-3_px"] >= 0.98 and d["exact_variant_ms_per_step"] > 0
+    assert d["parity"]["frac_within_1e-3_px"] >= tol.FAST_FRAC_WITHIN_1E3_PX and d["exact_variant_ms_per_step"] > 0
+    assert d["parity_violations"] == []
+
+
+def test_bench_fast_variant_states_and_meets_its_tolerance():
+    """bench.py --fast: the tolerance-checked variants; the line states src/tolerances.py's limits, measures them on the
+    timed pair and the script would exit non-zero on a violation."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--config", "cfg1", "--fast",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    d = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
+    assert d["roofline"]["kernel"] == "cbca_iter_pair" and d["config"]["variant"].startswith("fast")
+    assert "split-f16" in d["dtype"] and d["parity_violations"] == [] and d["exact_variant_ms_per_step"] > 0
+    pp = d["parity"]
+    assert not tol.fast_violations(pp["pixels"], pp["wta_flips_left"], pp["wta_flips_right"], pp["frac_within_1e-3_px"],
+                                   pp["p99.9_abs_px"])
 
 
 def test_bench_world_size_one_through_rccl():
@@ -135,7 +155,13 @@ def test_bench_world_size_one_through_rccl():
     d = json.loads(lines[0])
     assert d["process_group"] == "nccl x1", d["process_group"]
     assert d["n_gpus"] == 1 and d["config"]["launch"] == "one hipGraph replay per pair"
-    assert d["roofline"]["kernel"] == "cbca_iter_pair" and 0.0 < d["roofline"]["frac"] < 1.5
+    # the benchmarked variant is the drop-in default: float32, bit-exact, its twin agrees bit for bit
+    assert d["roofline"]["kernel"] == "cbca_iter_hwd_pair" and 0.0 < d["roofline"]["frac"] < 1.5
+    assert d["dtype"] == "f32" and d["config"]["variant"].startswith("bit-exact")
+    assert d["parity"]["final_map_bit_identical"] and d["parity"]["timed_path_equals_kernel_by_kernel"]
+    assert d["parity_violations"] == [] and d["fast_variant_ms_per_step"] > 0
+    assert d["fast_variant_parity"]["violations"] == [], d["fast_variant_parity"]
+    assert len(d["per_rank_device"]) == 1 and d["per_rank_device"][0]["device"] == 0
     want = 256 * 256 * 64 * 1e-6 / (d["ms_per_step"] * 1e-3)
     assert abs(d["value"] - want) <= 0.02 * want
     assert d["ms_per_step_host_in_host_out"] > 0 and d["ms_per_step_kernel_by_kernel"] > 0

@@ -13,6 +13,8 @@ import numpy as np
 import pytest
 import torch
 
+import tolerances as tol
+
 from conftest import ROOT
 from helpers import assert_bits
 
@@ -126,8 +128,8 @@ def test_cfg1_whole_pair_stage_by_stage(net_layers):
         "max_abs_px": float(np.nanmax(np.abs(split_map - exact_map)))}
     _dump()
     assert RECORD["cfg1_split_features_max_abs_vs_float64_restatement"] <= 1e-5
-    assert flips_s <= split_map.size // 500, "split features: %d WTA flips of %d" % (flips_s, split_map.size)
-    assert close_s >= 0.985, "split features: only %.4f of the pixels within 1e-3 px of the bit-exact run" % close_s
+    assert flips_s <= tol.FAST_WTA_FLIP_FRACTION * split_map.size, "split features: %d WTA flips of %d" % (flips_s, split_map.size)
+    assert close_s >= tol.FAST_FRAC_WITHIN_1E3_PX, "split features: only %.4f of the pixels within 1e-3 px of the bit-exact run" % close_s
     assert cv_err <= 2e-6
     assert d["cbca_x2"] <= 2 * 8 * float(np.spacing(np.float32(1.0)))          # <= 8 spacings of max|input| per iteration
     # 16 iterations on post-SGM costs (|v| up to ~200), regions up to 729 pixels: measured 60 spacings of max|input|
@@ -136,11 +138,11 @@ def test_cfg1_whole_pair_stage_by_stage(net_layers):
     for k in ("sgm", "interpolation", "subpixel", "median", "bilateral"):       # these stages have no fast variant
         assert d[k] == 0.0, (k, d[k])
     assert d["wta_mismatches"] == 0
-    assert flips <= fast_map.size // 500, "fast variants flip %d WTA decisions of %d" % (flips, fast_map.size)
-    assert close >= 0.985, "only %.4f of the pixels within 1e-3 px of the bit-exact run" % close
+    assert flips <= tol.FAST_WTA_FLIP_FRACTION * fast_map.size, "fast variants flip %d WTA decisions of %d" % (flips, fast_map.size)
+    assert close >= tol.FAST_FRAC_WITHIN_1E3_PX, "only %.4f of the pixels within 1e-3 px of the bit-exact run" % close
 
 
-@pytest.mark.parametrize("cfg", ["cfg2", "cfg3"])
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4"])
 def test_benchmarked_path_against_bit_exact_variant_full_size(net_layers, cfg):
     """What bench.py times - fast variants + split-operand features, replayed as one hipGraph - at BASELINE's full
     sizes: (1) the replay is bit-identical to the same matcher launched kernel by kernel; (2) against the bit-exact
@@ -181,12 +183,11 @@ def test_benchmarked_path_against_bit_exact_variant_full_size(net_layers, cfg):
         "abs_px_99.9th_percentile": float(np.percentile(np.abs(a[fin] - b[fin]), 99.9)), "graph_replay_equals_eager": True,
         "exact_pixel_major_equals_plane_major": True}
     _dump()
-    # measured: 0 flips at cfg2, 2 of 931 500 at cfg3 (a flipped near-tie moves its pixel by many disparities, so the
-    # largest difference is not bounded; the 99.9th percentile is); 98.7-99.5 % within 1e-3 px (the sub-pixel parabola
-    # amplifies 1e-7-level differences of the features, so this fraction moves with MIOpen's choice of algorithm)
-    assert flips <= a.size // 10000, "%s: %d WTA flips" % (cfg, flips)
-    assert close >= 0.98, "%s: only %.4f within 1e-3 px" % (cfg, close)
-    assert float(np.percentile(np.abs(a[fin] - b[fin]), 99.9)) <= 0.1
+    # the stated tolerance of the fast variants (src/tolerances.py; the same constants at every configuration).
+    # Round 3 measured: 0 flips at cfg2, 2 of 931 500 at cfg3, 96 of 3 000 000 at cfg4; 98.7-99.5 % within 1e-3 px
+    bad = tol.fast_violations(a.size, int((kf["wta"][0] != ke["wta"][0]).sum()), int((kf["wta"][1] != ke["wta"][1]).sum()),
+                              close, float(np.percentile(np.abs(np.where(fin, a - b, np.inf)), 99.9)))
+    assert not bad, "%s: %s" % (cfg, "; ".join(bad))
 
 
 def test_cfg3_full_size_properties():
@@ -268,6 +269,84 @@ def test_cfg3_width_oracle_window():
     gdl, gdr = pf.disparity_prediction(a[0], a[1])
     assert_bits(gdl, odl, "wta W=1242")
     assert_bits(pf.interpolation(gdl, gdr, D), o.interpolation(odl, odr, D), "interpolation W=1242")
+
+
+@pytest.mark.parametrize("H,W,D", [(24, 750, 256), (20, 1242, 192), (12, 1500, 400)],
+                         ids=["cfg2_width_and_disparities", "cfg3_width_and_disparities", "cfg4_width_and_disparities"])
+def test_oracle_windows_at_real_width_and_disparity_range(H, W, D):
+    """The default (pixel-major, bit-exact) kernels against the CPU checker at the REAL width and the REAL disparity
+    range of cfg2 / cfg3 / cfg4 on a window of rows: cost volume written pixel-major -> CBCA x2 -> SGM_average -> CBCA
+    -> WTA (pf:78-113, 149-163, 187-235, 545-566, 245-254), every stage fed the GPU's own previous output.  750x256 is
+    one full 256-disparity chunk per wave, 1242x192 the three-disparities-per-lane kernels, 1500x400 two chunks (and
+    WTA as its own launch); the heights sit below / at the arm limit so the vertical arms clip at both borders."""
+    import oracle as o
+    import stereo_device as sd
+    import synthetic
+    rng = np.random.default_rng(H + W + D)
+    L, R, _, _, _ = synthetic.make_pair(H, W, D, seed=17)
+    l, r = dev(L[:, :, 0]), dev(R[:, :, 0])
+    f = rng.standard_normal((2, H, W, 64)).astype(np.float32)
+    f /= np.sqrt((f * f).sum(-1, keepdims=True)).astype(np.float32)
+    fl, fr = np.ascontiguousarray(f[0]), np.ascontiguousarray(f[1])
+    # a2
+    gl, gr = sd.cost_volume_hwd(dev(fl), dev(fr), D)
+    ol, orr = o.compute_cost_volume(fl, fr, D)
+    cl, cr = sd.hwd_to_dhw(gl, D).cpu().numpy(), sd.hwd_to_dhw(gr, D).cpu().numpy()
+    assert_bits(cl, ol, "cost volume %dx%d" % (W, D))
+    assert_bits(cr, orr, "cost volume %dx%d (right)" % (W, D))
+    # a4 x 2
+    sl, sr = sd.cross_arms_pair(l, r, 0.02, 14)
+    (gl, tl), (gr, tr) = sd.cbca_hwd_pair(gl, torch.empty_like(gl), sl, gr, torch.empty_like(gr), sr, D, 2, 14)
+    ol, orr = o.cost_volume_aggregation(L, R, cl, cr, 0.02, 14, 2)
+    cl, cr = sd.hwd_to_dhw(gl, D).cpu().numpy(), sd.hwd_to_dhw(gr, D).cpu().numpy()
+    assert_bits(cl, ol, "CBCA x2 %dx%d" % (W, D))
+    assert_bits(cr, orr, "CBCA x2 %dx%d (right)" % (W, D))
+    # a5 / a6
+    scratch = sd.sgm_scratch(H, W, D, l.device)
+    sd.sgm_average_hwd(l, r, [gl, gr], [0, 1], D, 2.3, 55.9, 4.0, 8.0, 0.08, 1.5, scratch)
+    ol, orr = o.SGM_average(cl.copy(), cr.copy(), L, R, 2.3, 55.9, 4, 8, 0.08, 1.5)
+    cl, cr = sd.hwd_to_dhw(gl, D).cpu().numpy(), sd.hwd_to_dhw(gr, D).cpu().numpy()
+    assert_bits(cl, ol, "SGM_average %dx%d" % (W, D))
+    assert_bits(cr, orr, "SGM_average %dx%d (right)" % (W, D))
+    # a4 again (3 iterations keep the checker in seconds), the last one carrying the WTA where one chunk holds D
+    fused = D <= sd.cbca_hwd_wta_max_d()
+    wl, wr = torch.empty((H, W), device="cuda"), torch.empty((H, W), device="cuda")
+    (gl, _), (gr, _) = sd.cbca_hwd_pair(gl, tl, sl, gr, tr, sr, D, 3, 14, wta_out=(wl, wr) if fused else None)
+    if not fused:
+        wl, wr = sd.wta_hwd(gl, D), sd.wta_hwd(gr, D)
+    ol, orr = o.cost_volume_aggregation(L, R, cl, cr, 0.02, 14, 3)
+    assert_bits(sd.hwd_to_dhw(gl, D).cpu().numpy(), ol, "CBCA x3 %dx%d" % (W, D))
+    assert_bits(sd.hwd_to_dhw(gr, D).cpu().numpy(), orr, "CBCA x3 %dx%d (right)" % (W, D))
+    # a7
+    odl, odr = o.disparity_prediction(ol, orr)
+    assert_bits(wl.cpu().numpy(), odl, "WTA %dx%d" % (W, D))
+    assert_bits(wr.cpu().numpy(), odr, "WTA %dx%d (right)" % (W, D))
+
+
+def test_sgm_infinite_costs_match_the_oracle():
+    """pf:545-566 with +inf costs scattered through both volumes (never a whole disparity vector): Python's min and
+    np.amin treat them like the kernel's v_min_f32 / v_min3_f32, every direction and side bit-exact.  NaN and -inf costs
+    are outside the kernel's contract (np.amin would turn the rest of the scanline into NaN, v_min_f32 drops a NaN
+    operand): INTEGRATION.md "Limits"."""
+    import oracle as o
+    import stereo_device as sd
+    import synthetic
+    H, W, D = 23, 61, 40
+    rng = np.random.default_rng(5)
+    L, R, _, _, _ = synthetic.make_pair(H, W, D, seed=21)
+    vols = []
+    for _ in range(2):
+        v = (rng.random((D, H, W), dtype=np.float32) * 4 - 2).astype(np.float32)
+        v[rng.random((D, H, W)) < 0.02] = np.inf
+        v[0][np.isinf(v).all(axis=0)] = 1.0
+        vols.append(v)
+    want = o.SGM_average(vols[0].copy(), vols[1].copy(), L, R, 2.3, 55.9, 4, 8, 0.08, 1.5)
+    l, r = dev(L[:, :, 0]), dev(R[:, :, 0])
+    hw = [sd.dhw_to_hwd(dev(v)) for v in vols]
+    sd.sgm_average_hwd(l, r, hw, [0, 1], D, 2.3, 55.9, 4.0, 8.0, 0.08, 1.5, sd.sgm_scratch(H, W, D, l.device))
+    assert np.isinf(want[0]).any() and not np.isnan(want[0]).all()
+    assert_bits(sd.hwd_to_dhw(hw[0], D).cpu().numpy(), want[0], "SGM_average with +inf costs (left)")
+    assert_bits(sd.hwd_to_dhw(hw[1], D).cpu().numpy(), want[1], "SGM_average with +inf costs (right)")
 
 
 def test_feature_row_tiling_matches_untiled_and_cfg4_memory(net_layers):

@@ -206,6 +206,37 @@ def test_cli_flags_match_reference():
                                                                          "timeMCCNN.txt")
 
 
+def test_gpu_flag_pins_the_card_only_when_given(monkeypatch):
+    """-g in every spelling argparse accepts (match.py:17, train.py:17) is explicit and overrides HIP_VISIBLE_DEVICES; the
+    default "0" only fills an empty environment; under torchrun (world > 1) the flag is ignored.  One helper for
+    match.py and train.py."""
+    import match
+    import train
+    import util
+    need = {match: ["--list_file", "l", "--data_dir", "d", "--save_dir", "s", "-t", "x", "-s", "0", "-e", "3"], train: ["--list_dir", "l", "--tensorboard_dir", "t", "--checkpoint_dir", "c"]}
+    for mod in (match, train):
+        for words, explicit, value in ((["-g", "3"], True, "3"), (["-g3"], True, "3"), (["--gpu=2"], True, "2"),
+                                       (["--gp", "5"], True, "5"), ([], False, "0")):
+            a = mod.parser.parse_known_args(need[mod] + words)[0]
+            assert (a.gpu, getattr(a, "gpu_explicit", False)) == (value, explicit), (mod.__name__, words)
+            monkeypatch.setenv("HIP_VISIBLE_DEVICES", "6")
+            util.pin_gpu(a, 1)
+            assert os.environ["HIP_VISIBLE_DEVICES"] == (value if explicit else "6")
+            monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+            util.pin_gpu(a, 1)
+            assert os.environ["HIP_VISIBLE_DEVICES"] == value and os.environ["CUDA_VISIBLE_DEVICES"] == value
+            monkeypatch.setenv("HIP_VISIBLE_DEVICES", "6")
+            util.pin_gpu(a, 8)
+            assert os.environ["HIP_VISIBLE_DEVICES"] == "6"
+
+
+def test_stated_tolerance_helper():
+    import tolerances as tol
+    assert tol.fast_violations(750000, 0, 0, 0.99, 0.05) == []
+    assert len(tol.fast_violations(750000, 76, 0, 0.97, 0.3)) == 3
+    assert tol.fast_violations(3000000, 96, 96, 0.988, 0.1) == []      # round 3's cfg4 numbers are inside the statement
+
+
 def test_synthetic_pairs_are_deterministic_and_standardised():
     import synthetic
     a = synthetic.make_pair(40, 60, 16, seed=5)

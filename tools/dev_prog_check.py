@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Dev harness (GPU box): launches the assembled program-driven aggregation kernel (csrc/asm/cbca_prog_gen.py) straight
-through the HIP module API with programs built by the plain-Python builder (tests/helpers/cbca_prog_ref.py), checks it
+through the HIP module API with programs built by the plain-Python builder (tests/asmtools/cbca_prog_ref.py), checks it
 bit for bit against cbca_hwd_kernel and times both.
     python tools/dev_prog_check.py [--config cfg2] [--iters 10] [--w 12] [--small-only]"""
 import argparse
@@ -11,7 +11,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in ("mc-cnn-python_amd/src", "mc-cnn-python_amd/csrc/asm", "tests/helpers", ""):
+for p in ("mc-cnn-python_amd/src", "mc-cnn-python_amd/csrc/asm", "tests/asmtools", ""):
     sys.path.insert(0, os.path.join(ROOT, p))
 import numpy as np
 import torch

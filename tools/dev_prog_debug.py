@@ -2,7 +2,7 @@
 """Dev (GPU box): one small case through the assembled kernel, the simulator and cbca_hwd; prints where they differ."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in ("mc-cnn-python_amd/src", "mc-cnn-python_amd/csrc/asm", "tests/helpers", "tests", "oracle", ""):
+for p in ("mc-cnn-python_amd/src", "mc-cnn-python_amd/csrc/asm", "tests/asmtools", "tests", "oracle", ""):
     sys.path.insert(0, os.path.join(ROOT, p))
 import numpy as np, torch
 import stereo_device as sd, synthetic, cbca_prog_gen as gen, cbca_prog_ref as ref, asm_sim
