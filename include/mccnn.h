@@ -45,7 +45,7 @@ extern "C" {
 
 typedef void *mccnn_stream_t; /* hipStream_t */
 
-#define MCCNN_ABI_VERSION 2 /* 2: support buffer grew by the window-mask plane (22 B / pixel), *_hwd entry points */
+#define MCCNN_ABI_VERSION 3 /* 2: window-mask plane in the support buffer, *_hwd entry points; 3: saturation flags */
 
 #define MCCNN_E_INVALID (-1)     /* bad argument (null pointer, non-positive size, unsupported shape) */
 #define MCCNN_E_UNSUPPORTED (-2) /* shape outside what the kernels were built for (e.g. D > 512 for SGM) */
@@ -247,10 +247,14 @@ int mccnn_conv1_pad_bias_relu(const float *images, const float *weights, const f
 int mccnn_l2norm_chw_to_hwc(const float *chw, const float *bias, float *hwc, int C, int H, int W,
                             mccnn_stream_t stream);
 
-/* ---- a1 on the matrix cores: split-operand 3x3 convolutions (opt-in; model.py:51-64) ----------------------------
+/* ---- a1 on the matrix cores: split-operand 3x3 convolutions (the default feature path; model.py:51-64) ---------
  * The 64 -> 64 map layers as an implicit GEMM on v_mfma_f32_32x32x16_f16 with every float32 operand carried as two
- * f16 numbers (x * s = hi + lo, 22 significand bits; products hi*hi + hi*lo + lo*hi accumulated in float32): as close
- * to a float64 evaluation as the float32 library convolutions, but not bit-identical to them, hence opt-in.
+ * f16 numbers (x * s = hi + lo, 22 significand bits; products hi*hi and hi*lo + lo*hi accumulated in float32 in two
+ * accumulator sets that meet once per output): as close to a float64 evaluation as the float32 library convolutions
+ * (2.5e-7 .. 3e-7 on the unit feature vectors for both), not bit-identical to them.
+ * saturation_flag (device int, may be NULL): set to 1 when a stored activation exceeds the f16 range of the records
+ * (|x| * act_scale > 65504; the value is clamped, the features are then NOT float32-accurate).  The caller zeroes
+ * it, reads it back after the pair and recomputes with the float32 library path if it is set (match.py does).
  * "Split records": 256 bytes per pixel, [channel group q of 16][hi: 16 x f16 | lo: 16 x f16], pixel-major
  * [N][H][W][256 B]; act_scale (a power of two, e.g. 256) is the factor the stored activations carry (they saturate
  * at |x| * act_scale = 65504).
@@ -265,9 +269,9 @@ int mccnn_l2norm_chw_to_hwc(const float *chw, const float *bias, float *hwc, int
 size_t mccnn_conv3x3_split_weights_bytes(void);
 int mccnn_conv3x3_split_pack(const float *weights, float weight_scale, void *packed, mccnn_stream_t stream);
 int mccnn_conv1_split(const float *images, const float *weights, const float *bias, void *out, int N, int H, int W,
-                      int pad, float act_scale, mccnn_stream_t stream);
+                      int pad, float act_scale, int *saturation_flag, mccnn_stream_t stream);
 int mccnn_conv3x3_split(const void *in, const void *packed_weights, const float *bias, void *out, int N, int Hi, int Wi,
-                        float weight_scale, float act_scale, int last, mccnn_stream_t stream);
+                        float weight_scale, float act_scale, int last, int *saturation_flag, mccnn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -6,11 +6,11 @@
 // as two f16 numbers, x * s = hi + lo with hi = f16(x * s), lo = f16(x * s - hi) (s a power of two chosen so that
 // both parts stay normal numbers): 22 significand bits.  A product a * b becomes three MFMA terms
 //     a_hi * b_hi + a_hi * b_lo + a_lo * b_hi          (the a_lo * b_lo term is below 2^-22 relative)
-// accumulated in float32 by the matrix core.  Measured against a float64 evaluation of the stack the unit feature
-// vectors are off by 5e-7 where the float32 library path is off by 2.5e-7 (tests/test_features_split_gpu.py records
-// both; the golden feature test allows 1e-5) - float32-class arithmetic on f16 hardware, not a reduced-precision mode,
-// but NOT bit-identical to any float32 evaluation order, so it is selected explicitly
-// (StereoMatcher(features="split_f16"), match.py --fast).
+// accumulated in float32 by the matrix core - the main term and the two cross terms in accumulators of their own
+// (round 4; see the kernel).  Measured against a float64 evaluation of the stack the unit feature vectors are as close
+// as the float32 library path's (tests/test_features_split_gpu.py records both; round 2's single accumulator was twice
+// as far: 5.3e-7 vs 2.5e-7) - float32-class arithmetic on f16 hardware, not a reduced-precision mode, but NOT
+// bit-identical to any float32 evaluation order.
 //
 // Activations live in HBM as "split records": 256 bytes per pixel, [q = channel / 16][hi 16 x f16 | lo 16 x f16],
 // pixel-major ([N][H][W][256 B]).  A record has the size of the pixel's 64 float32 values; the last layer writes those
@@ -118,7 +118,8 @@ __global__ __launch_bounds__(256) void conv3x3_split_pack_kernel(const float *__
 // multiply-adds as mccnn_conv1_pad_bias_relu, then the split; a lane writes its pixel's record in 16-byte pieces.
 __global__ __launch_bounds__(256) void conv1_split_kernel(const float *__restrict__ img, const float *__restrict__ w,
                                                           const float *__restrict__ bias, char *__restrict__ out, int H,
-                                                          int W, int pad, int Ho, int Wo, float act_scale)
+                                                          int W, int pad, int Ho, int Wo, float act_scale,
+                                                          int *__restrict__ sat_flag)
 {
     const int xo = blockIdx.x * 256 + threadIdx.x;
     const int yo = blockIdx.y, n = blockIdx.z;
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(256) void conv1_split_kernel(const float *__restric
             v[i * 3 + j] = (y >= 0 && y < H && x >= 0 && x < W) ? img[((size_t)n * H + y) * W + x] : 0.f;
         }
     char *rec = out + (((size_t)n * Ho + yo) * Wo + xo) * cs::REC;
+    bool sat = false;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         w2 hi[4], lo[4];
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(256) void conv1_split_kernel(const float *__restric
                 for (int k = 0; k < 9; ++k) acc += w[c * 9 + k] * v[k];
                 acc += bias[c];
                 y[j] = fmaxf(acc, 0.f);
+                sat |= !(y[j] * act_scale <= 65504.f);        // also true for NaN
             }
             split4(y, act_scale, hi[g], lo[g]);
         }
@@ -155,6 +158,7 @@ __global__ __launch_bounds__(256) void conv1_split_kernel(const float *__restric
         p[2] = w4{lo[0].x, lo[0].y, lo[1].x, lo[1].y};
         p[3] = w4{lo[2].x, lo[2].y, lo[3].x, lo[3].y};
     }
+    if (sat_flag && sat) atomicOr(sat_flag, 1);              // a stored activation left the f16 range (see mccnn.h)
 }
 
 __device__ __forceinline__ void pin_loads()
@@ -168,7 +172,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restrict__ in, const char *__restrict__ wpk,
                                                             const float *__restrict__ bias, char *__restrict__ out,
                                                             int N, int Hi, int Wi, float inv_scale, float act_scale,
-                                                            int tiles_x, int tiles_y, int total)
+                                                            int tiles_x, int tiles_y, int total,
+                                                            int *__restrict__ sat_flag)
 {
     using namespace cs;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -249,13 +254,19 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
     char *const epi = lds + 2 * QBUF + wave * EPI;
 
     while (true) {
-        f16x acc[NBW][2];
+        // Two accumulator sets.  The matrix core rounds its float32 accumulator once per MFMA; with the three products
+        // of a K step chained into ONE accumulator that is 108 roundings at the full magnitude of the sum per output,
+        // against 36 for a float32 convolution - and that, not the 22-bit operands, was what made round 2's kernel
+        // twice as far from a float64 evaluation as the library (5.3e-7 vs 2.5e-7).  The cross terms
+        // a_lo b_hi + a_hi b_lo are 2^-11 of the main term, so they get an accumulator of their own (its roundings
+        // are 2^-11 as large) and meet the main sum once, in the epilogue: float32-accumulation accuracy.
+        f16x acc[NBW][2], accx[NBW][2];
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[nb][mb][i] = 0.f;
+                for (int i = 0; i < 16; ++i) acc[nb][mb][i] = accx[nb][mb][i] = 0.f;
         const int vn = v + gridDim.x;
         int nn = 0, nty0 = 0, ntx0 = 0;
         if (vn < total) tile_base(vn, nn, nty0, ntx0);
@@ -304,10 +315,10 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
                     __builtin_amdgcn_sched_barrier(0);   // the reads above are issued before the MFMAs below
                     const h8 b_hi = __builtin_bit_cast(h8, bf[step & 1][0]);
                     const h8 b_lo = __builtin_bit_cast(h8, bf[step & 1][1]);
-                    acc[nb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo0, b_hi, acc[nb][0], 0, 0, 0);
-                    acc[nb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo1, b_hi, acc[nb][1], 0, 0, 0);
-                    acc[nb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi0, b_lo, acc[nb][0], 0, 0, 0);
-                    acc[nb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi1, b_lo, acc[nb][1], 0, 0, 0);
+                    accx[nb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo0, b_hi, accx[nb][0], 0, 0, 0);
+                    accx[nb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo1, b_hi, accx[nb][1], 0, 0, 0);
+                    accx[nb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi0, b_lo, accx[nb][0], 0, 0, 0);
+                    accx[nb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi1, b_lo, accx[nb][1], 0, 0, 0);
                     acc[nb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi0, b_hi, acc[nb][0], 0, 0, 0);
                     acc[nb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi1, b_hi, acc[nb][1], 0, 0, 0);
                 }
@@ -327,6 +338,7 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
 
         // ---- epilogue: this wave's four rows of 32 pixels ----
         const int px = lane & 31, half = lane >> 5;
+        bool sat = false;
 #ifdef CONV_ABL_NOEPI   // timing experiment: one store per accumulator so the MFMAs stay live
         {
             float t = 0.f;
@@ -335,7 +347,7 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) t += acc[nb][mb][r];
+                    for (int r = 0; r < 16; ++r) t += acc[nb][mb][r] + accx[nb][mb][r];
             if (t == 123.456f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t), rs_out, lane * 4, 0, 0);
         }
 #else
@@ -349,10 +361,11 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
                 for (int r = 0; r < 16; ++r) {
                     const int ch = 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * half;
                     if (MODE == 0) {
-                        const float t = fmaf(acc[nb][mb][r], inv_scale * act_scale, bias[ch] * act_scale);
+                        const float t = fmaf(acc[nb][mb][r] + accx[nb][mb][r], inv_scale * act_scale, bias[ch] * act_scale);
+                        sat |= !(t <= 65504.f);                       // also true for NaN
                         y[mb][r] = __builtin_amdgcn_fmed3f(t, 0.f, 65504.f);
                     } else {
-                        const float t = fmaf(acc[nb][mb][r], inv_scale, bias[ch]);
+                        const float t = fmaf(acc[nb][mb][r] + accx[nb][mb][r], inv_scale, bias[ch]);
                         y[mb][r] = t;
                         ss = fmaf(t, t, ss);
                     }
@@ -406,6 +419,9 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
             }
             __builtin_amdgcn_wave_barrier();
         }
+        // a stored activation left the f16 range of the records (|x| * act_scale > 65504): the clamp keeps the data
+        // finite, the flag tells the host that this pair's features are not float32-accurate (mccnn.h)
+        if (MODE == 0 && sat_flag && __builtin_amdgcn_ballot_w64(sat) != 0 && lane == 0) atomicOr(sat_flag, 1);
 #endif
         if (vn >= total) break;
         v = vn;
@@ -430,7 +446,7 @@ extern "C" int mccnn_conv3x3_split_pack(const float *weights, float weight_scale
 }
 
 extern "C" int mccnn_conv1_split(const float *images, const float *weights, const float *bias, void *out, int N, int H,
-                                 int W, int pad, float act_scale, mccnn_stream_t stream)
+                                 int W, int pad, float act_scale, int *saturation_flag, mccnn_stream_t stream)
 {
     using namespace mccnn;
     MCCNN_REQUIRE(images && weights && bias && out, MCCNN_E_INVALID, "mccnn_conv1_split: null pointer");
@@ -440,13 +456,13 @@ extern "C" int mccnn_conv1_split(const float *images, const float *weights, cons
     MCCNN_REQUIRE(Ho > 0 && Wo > 0 && Ho <= 65535 && N <= 65535, MCCNN_E_UNSUPPORTED,
                   "mccnn_conv1_split: output %dx%d outside the grid", Wo, Ho);
     hipLaunchKernelGGL(conv1_split_kernel, dim3(cdiv(Wo, 256), Ho, N), dim3(256), 0, (hipStream_t)stream, images,
-                       weights, bias, reinterpret_cast<char *>(out), H, W, pad, Ho, Wo, act_scale);
+                       weights, bias, reinterpret_cast<char *>(out), H, W, pad, Ho, Wo, act_scale, saturation_flag);
     return check_launch("mccnn_conv1_split");
 }
 
 extern "C" int mccnn_conv3x3_split(const void *in, const void *packed_weights, const float *bias, void *out, int N,
                                    int Hi, int Wi, float weight_scale, float act_scale, int last,
-                                   mccnn_stream_t stream)
+                                   int *saturation_flag, mccnn_stream_t stream)
 {
     using namespace mccnn;
     using namespace cs;
@@ -470,14 +486,16 @@ extern "C" int mccnn_conv3x3_split(const void *in, const void *packed_weights, c
         MCCNN_REQUIRE(attr == hipSuccess, MCCNN_E_UNSUPPORTED, "mccnn_conv3x3_split: %d bytes of LDS refused", LDS_BYTES);
         hipLaunchKernelGGL(conv3x3_split_kernel<1>, dim3(grid), dim3(256), LDS_BYTES, s,
                            reinterpret_cast<const char *>(in), reinterpret_cast<const char *>(packed_weights), bias,
-                           reinterpret_cast<char *>(out), N, Hi, Wi, inv, act_scale, tiles_x, tiles_y, (int)total);
+                           reinterpret_cast<char *>(out), N, Hi, Wi, inv, act_scale, tiles_x, tiles_y, (int)total,
+                           saturation_flag);
     } else {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_split_kernel<0>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         MCCNN_REQUIRE(attr == hipSuccess, MCCNN_E_UNSUPPORTED, "mccnn_conv3x3_split: %d bytes of LDS refused", LDS_BYTES);
         hipLaunchKernelGGL(conv3x3_split_kernel<0>, dim3(grid), dim3(256), LDS_BYTES, s,
                            reinterpret_cast<const char *>(in), reinterpret_cast<const char *>(packed_weights), bias,
-                           reinterpret_cast<char *>(out), N, Hi, Wi, inv, act_scale, tiles_x, tiles_y, (int)total);
+                           reinterpret_cast<char *>(out), N, Hi, Wi, inv, act_scale, tiles_x, tiles_y, (int)total,
+                           saturation_flag);
     }
     return check_launch("mccnn_conv3x3_split");
 }

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MCCNN_HIP_LIB selects another build of the same library (kernel A/B measurements); there is still no CPU path.
 LIB_PATH = os.environ.get("MCCNN_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libmccnn_hip.so")
 
-MCCNN_ABI_VERSION = 2      # include/mccnn.h; load() refuses a library built from another header
+MCCNN_ABI_VERSION = 3      # include/mccnn.h; load() refuses a library built from another header
 MCCNN_CV_EXACT = 0
 MCCNN_CV_MFMA = 1
 MCCNN_CBCA_SEPARABLE = 0
@@ -66,8 +66,8 @@ SIGNATURES = {
     "mccnn_conv1_pad_bias_relu": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mccnn_conv3x3_split_weights_bytes": (_sz, []),
     "mccnn_conv3x3_split_pack": (_i, [_vp, _f, _vp, _vp]),
-    "mccnn_conv1_split": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
-    "mccnn_conv3x3_split": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
+    "mccnn_conv1_split": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
+    "mccnn_conv3x3_split": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp]),
     "mccnn_l2norm_chw_to_hwc": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
 }
 

@@ -165,6 +165,10 @@ class NET(object):
         out = self._convs_device(image_hw[None], pad)[0]      # [64,H,W] without the last bias
         return stereo_device.l2norm_chw_to_hwc(out, self.biases[-1])
 
+    def supports_split_features(self):
+        """The hand-written matrix-core feature kernels are built for 3x3 convolutions, 64 maps, >= 2 layers."""
+        return self.conv_kernel_size == 3 and self.num_conv_feature_maps == 64 and self.num_conv_layers >= 2
+
     def _split_weights(self):
         """Packed f16 hi/lo weights of layers 2..n for the split-operand kernels, rebuilt when a weight tensor changes."""
         import stereo_device
@@ -173,33 +177,42 @@ class NET(object):
         if cache is None or cache[0] != key:
             cache = (key, [stereo_device.conv3x3_split_pack(w) for w in self.weights[1:]])
             self._split_cache = cache
-            # Range check, once per weight set: the split records saturate at |x| = 65504 / act_scale (256 -> 255.9)
-            # and nothing downstream would notice.  A probe image of standardised-intensity range through the float32
-            # stack must stay a factor 4 below that at every layer (the trained checkpoint peaks at ~6).
-            with torch.no_grad():
-                g = torch.Generator().manual_seed(1)
-                probe = (torch.randn((1, 1, 48, 48), generator=g) * 2.0).clamp(-6, 6).to(self.device)
-                peak = max(float(o.abs().max()) for o in self._convs_nchw(probe))
-            self._split_range_ok = peak < 0.25 * 65504.0 / stereo_device.SPLIT_ACT_SCALE
         return cache[1]
+
+    def _split_flag(self):
+        """Device int the split kernels set when an activation leaves the f16 range of the stored records
+        (|x| >= 65504 / act_scale = 255.9; the trained checkpoint peaks near 6 on standardised images).  Round 3
+        guessed the range from a probe image; the kernels now report what actually happened."""
+        f = getattr(self, "_split_sat", None)
+        if f is None or f.device != self.weights[0].device:
+            f = torch.zeros((1,), dtype=torch.int32, device=self.weights[0].device)
+            self._split_sat = f
+        return f
+
+    def split_saturated(self, reset=True):
+        """True when a split-operand feature launch since the last reset clamped an activation (one .item() sync)."""
+        f = getattr(self, "_split_sat", None)
+        if f is None:
+            return False
+        hit = bool(int(f.item()))
+        if hit and reset:
+            f.zero_()
+        return hit
 
     def features_pair_hwc_split(self, left_hw, right_hw):
         """features_pair_hwc on the matrix cores (csrc/conv_mfma.hip): every float32 operand as two f16 numbers, three
-        MFMA products per multiply, float32 accumulation - as close to a float64 evaluation as the library path, not
-        bit-identical to it (opt-in: StereoMatcher(features="split_f16"), match.py --fast).  Needs the 64-map 3x3
-        topology with at least two layers; activations must stay below 65504 / 256 in magnitude."""
+        MFMA products per multiply, float32 accumulation (main and cross terms in accumulators of their own) - as
+        close to a float64 evaluation as the library path, not bit-identical to it.  The default feature path of
+        StereoMatcher / match.py / process_functional.compute_features.  Needs the 64-map 3x3 topology with at least
+        two layers; activations must stay below 65504 / 256 in magnitude - split_saturated() tells if one did not."""
         import warnings
         import stereo_device
         pad = (self.input_patch_size - 1) // 2
         assert pad == self.num_conv_layers * (self.conv_kernel_size - 1) // 2
-        if self.conv_kernel_size != 3 or self.num_conv_feature_maps != 64 or self.num_conv_layers < 2:
+        if not self.supports_split_features():
             raise ValueError("the split-operand feature kernels are built for >= 2 layers of 64 maps, 3x3")
         packed = self._split_weights()
-        if not self._split_range_ok:
-            warnings.warn("split-operand features: this weight set drives activations beyond the f16 range of the "
-                          "stored records (|x| < %.0f); using the float32 library convolutions instead"
-                          % (65504.0 / stereo_device.SPLIT_ACT_SCALE))
-            return self.features_pair_hwc(left_hw, right_hw)
+        flag = self._split_flag()
         H, W = left_hw.shape
         # the kernels address their records with 32-bit byte offsets: 256 B per padded pixel, both views in one batch
         limit = 0x7ffffff0 // 256
@@ -214,10 +227,11 @@ class NET(object):
         outs = []
         nl = self.num_conv_layers
         for views in batches:
-            x = stereo_device.conv1_split(views, self.weights[0].detach().contiguous(), self.biases[0].detach(), pad)
+            x = stereo_device.conv1_split(views, self.weights[0].detach().contiguous(), self.biases[0].detach(), pad,
+                                          sat_flag=flag)
             for k in range(1, nl):
                 pk, ws = packed[k - 1]
-                x = stereo_device.conv3x3_split(x, pk, ws, self.biases[k].detach(), last=(k == nl - 1))
+                x = stereo_device.conv3x3_split(x, pk, ws, self.biases[k].detach(), last=(k == nl - 1), sat_flag=flag)
             outs += [x[i] for i in range(x.shape[0])]
         return outs[0], outs[1]
 

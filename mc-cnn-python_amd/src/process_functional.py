@@ -31,6 +31,7 @@ import _hipabi as hip
 import stereo_device as sd
 from model import NET
 
+FEATURES = "split_f16"       # "split_f16": hand-written matrix-core conv stack (float32-accurate); "library": MIOpen
 COST_VOLUME_MODE = "exact"
 CBCA_ORDER = "reference"
 CBCA_BOTH_VIEWS = False
@@ -89,6 +90,12 @@ def compute_features(left_image, right_image, patch_height, patch_width, checkpo
     L, was_np = _img(left_image)
     R, _ = _img(right_image)
     net = checkpoint if isinstance(checkpoint, NET) else _net_for(checkpoint, patch_height)
+    if FEATURES == "split_f16" and net.supports_split_features():
+        # the hand-written matrix-core stack (float32-accurate; csrc/conv_mfma.hip); should an activation leave the
+        # range of its stored records, the float32 library convolutions take the pair instead
+        fl, fr = net.features_pair_hwc_split(L, R)
+        if not net.split_saturated():
+            return _ret(fl, was_np), _ret(fr, was_np)
     return _ret(net.features_hwc(L), was_np), _ret(net.features_hwc(R), was_np)
 
 

@@ -102,17 +102,19 @@ def conv3x3_split_pack(weight):
     return packed, scale
 
 
-def conv1_split(images, weight, bias, pad, act_scale=SPLIT_ACT_SCALE):
-    """images [N,H,W] -> split records [N,H+2pad-2,W+2pad-2,256] (uint8 view): padding + layer 1 + bias + ReLU."""
+def conv1_split(images, weight, bias, pad, act_scale=SPLIT_ACT_SCALE, sat_flag=None):
+    """images [N,H,W] -> split records [N,H+2pad-2,W+2pad-2,256] (uint8 view): padding + layer 1 + bias + ReLU.
+    sat_flag: int32 device tensor [1] that the kernel sets when an activation leaves the records' f16 range."""
     N, H, W = images.shape
     assert tuple(weight.shape) == (64, 1, 3, 3) and images.is_contiguous() and weight.is_contiguous()
     out = torch.empty((N, H + 2 * pad - 2, W + 2 * pad - 2, 256), dtype=torch.uint8, device=images.device)
     hip.check(hip.load().mccnn_conv1_split(hip.ptr(images), hip.ptr(weight), hip.ptr(bias), hip.ptr(out), N, H, W,
-                                           int(pad), float(act_scale), hip.stream()), "mccnn_conv1_split")
+                                           int(pad), float(act_scale), hip.ptr(sat_flag) if sat_flag is not None else None,
+                                           hip.stream()), "mccnn_conv1_split")
     return out
 
 
-def conv3x3_split(x, packed, weight_scale, bias, last, act_scale=SPLIT_ACT_SCALE):
+def conv3x3_split(x, packed, weight_scale, bias, last, act_scale=SPLIT_ACT_SCALE, sat_flag=None):
     """x: split records [N,Hi,Wi,256] -> VALID 3x3 conv + bias; last=False: ReLU, records [N,Hi-2,Wi-2,256];
     last=True: L2-normalised float32 features [N,Hi-2,Wi-2,64]."""
     N, Hi, Wi, rec = x.shape
@@ -122,7 +124,8 @@ def conv3x3_split(x, packed, weight_scale, bias, last, act_scale=SPLIT_ACT_SCALE
     else:
         out = torch.empty((N, Hi - 2, Wi - 2, 256), dtype=torch.uint8, device=x.device)
     hip.check(hip.load().mccnn_conv3x3_split(hip.ptr(x), hip.ptr(packed), hip.ptr(bias), hip.ptr(out), N, Hi, Wi,
-                                             float(weight_scale), float(act_scale), 1 if last else 0, hip.stream()),
+                                             float(weight_scale), float(act_scale), 1 if last else 0,
+                                             hip.ptr(sat_flag) if sat_flag is not None else None, hip.stream()),
               "mccnn_conv3x3_split")
     return out
 
@@ -548,10 +551,12 @@ class StereoMatcher(object):
     tolerance-bounded variant of those two stages.  NOTE (round 3 on): the defaults are the bit-exact variants
     (MCCNN_CV_EXACT, MCCNN_CBCA_REFERENCE_ORDER: 13.7 ms per Middlebury-half pair); callers that relied on the
     earlier default (the fast variants, 9.3 ms) must ask for MCCNN_CV_MFMA / MCCNN_CBCA_SEPARABLE explicitly.
+    features_saturated() tells (with one host synchronisation) whether a pair since the last check drove an
+    activation out of the split records' range - the caller then repeats that pair with features="miopen".
     """
 
     def __init__(self, net, hp=None, cv_mode=hip.MCCNN_CV_EXACT, cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER,
-                 feature_tile_rows=None, extras=None, features="miopen", layout="auto"):
+                 feature_tile_rows=None, extras=None, features="auto", layout="auto"):
         self.device = hip.require_device()
         self.net = net
         self.hp = dict(DEFAULT_HP)
@@ -560,11 +565,16 @@ class StereoMatcher(object):
         self.cv_mode = cv_mode
         self.cbca_order = cbca_order
         self.feature_tile_rows = feature_tile_rows   # None: whole image; else NET.features_pair_hwc's band height
-        # "miopen": float32 library convolutions; "split_f16": the split-operand matrix-core kernels (conv_mfma.hip)
-        if features not in ("miopen", "split_f16"):
-            raise ValueError("features must be 'miopen' or 'split_f16'")
+        # "split_f16": the split-operand matrix-core kernels (conv_mfma.hip; float32-accurate since round 4: as close to
+        # a float64 evaluation as the library); "miopen": float32 library convolutions; "auto" (default): the
+        # hand-written kernels where the network has their topology (3x3, 64 maps, >= 2 layers) and no row banding
+        # is asked for, the library otherwise
+        if features not in ("auto", "miopen", "split_f16"):
+            raise ValueError("features must be 'auto', 'miopen' or 'split_f16'")
         if features == "split_f16" and feature_tile_rows is not None:
             raise ValueError("row banding is implemented for the library convolutions only")
+        if features == "auto":
+            features = "split_f16" if (feature_tile_rows is None and net.supports_split_features()) else "miopen"
         self.features = features
         # "auto": the bit-exact variant runs on pixel-major volumes (pixel_major()); "plane_major" keeps every stage
         # on the reference's [D,H,W] layout (the round-2 kernels: cross-checks, and what the fast variant always uses)
@@ -583,6 +593,10 @@ class StereoMatcher(object):
         self._ws = {}
         self._graphs = {}
         self._side = None
+
+    def features_saturated(self, reset=True):
+        """True when the split-operand feature kernels clamped an activation since the last reset (blocks the host)."""
+        return self.net.split_saturated(reset)
 
     def workspace(self, H, W, D):
         key = (H, W, D)

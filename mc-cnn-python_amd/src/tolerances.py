@@ -12,19 +12,24 @@ float32 running sum (<= 8 float32 spacings of the largest cost per iteration, CB
 the aggregated costs, so a pixel can flip only where two disparities tie to within that error (FAST_WTA_FLIP_FRACTION
 of the pixels; a flipped near-tie moves its pixel by many disparities, which is why no maximum is stated).  The
 sub-pixel parabola divides a cost difference by a second difference that is small on flat cost curves, which turns 1e-6
-cost differences into 1e-3 .. 1e-1 px there: hence a fraction within 1e-3 px and a high percentile instead of a bound."""
+cost differences into 1e-3 .. 1e-1 px there: hence a fraction within 1e-3 px and a percentile instead of a bound."""
 
 FEATURES_ABS = 1e-5                 # unit feature vectors vs the float64 restatement (SURVEY App. D a1)
-FEATURES_SPLIT_ABS = 2e-6           # the split-operand kernels vs a float64 evaluation by torch on the CPU
+FEATURES_F32_CLASS_ABS = 5e-7       # EITHER feature path (library float32 / hand-written split-operand kernels) vs a
+                                    # float64 evaluation of the network by torch on the CPU, same bound for both
 COST_VOLUME_MFMA_ABS = 2e-6         # matrix-core cost volume vs the exact one (SURVEY App. D a2)
 CBCA_SPACINGS = 8                   # separable aggregation, per iteration, in float32 spacings of max |cost|
 
 FAST_WTA_FLIP_FRACTION = 1e-4       # WTA indices that may differ from the bit-exact variant, per pixel and view
 FAST_FRAC_WITHIN_1E3_PX = 0.98      # fraction of the final map within 1e-3 px of the bit-exact variant
-FAST_P999_ABS_PX = 0.25             # 99.9th percentile of |final map - bit-exact final map| in px
+FAST_P99_ABS_PX = 0.02              # 99th percentile of |final map - bit-exact final map| in px
+# (Stated as the 99.9th percentile <= 0.25 px at first; the first measurement showed that statistic to be ill-defined:
+# in the BIT-EXACT variant's own map 0.01 .. 0.2 % of the pixels lie beyond the disparity range, |value| > D, because
+# the reference's sub-pixel formula divides by a second difference it does not guard (pf:387-396) - on those pixels any
+# two evaluations differ by whole pixels.  The 99th percentile is free of them at every configuration.)
 
 
-def fast_violations(pixels, flips_left, flips_right, frac_within_1e3, p999_abs_px):
+def fast_violations(pixels, flips_left, flips_right, frac_within_1e3, p99_abs_px):
     """The list of stated limits a fast-variant run breaks (empty = inside its stated tolerance)."""
     bad = []
     lim = FAST_WTA_FLIP_FRACTION * pixels
@@ -33,6 +38,6 @@ def fast_violations(pixels, flips_left, flips_right, frac_within_1e3, p999_abs_p
                                                                          FAST_WTA_FLIP_FRACTION, pixels))
     if frac_within_1e3 < FAST_FRAC_WITHIN_1E3_PX:
         bad.append("only %.4f of the final map within 1e-3 px (stated: >= %.2f)" % (frac_within_1e3, FAST_FRAC_WITHIN_1E3_PX))
-    if p999_abs_px > FAST_P999_ABS_PX:
-        bad.append("99.9th percentile %.4f px (stated: <= %.2f)" % (p999_abs_px, FAST_P999_ABS_PX))
+    if p99_abs_px > FAST_P99_ABS_PX:
+        bad.append("99th percentile %.4f px (stated: <= %.2f)" % (p99_abs_px, FAST_P99_ABS_PX))
     return bad

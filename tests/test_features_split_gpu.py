@@ -1,4 +1,4 @@
-"""GPU: the split-operand (f16 hi/lo, three MFMA products) feature stack of csrc/conv_mfma.hip - SURVEY 8 a1, opt-in.
+"""GPU: the split-operand (f16 hi/lo, three MFMA products) feature stack of csrc/conv_mfma.hip - SURVEY 8 a1, the default.
 
 Checker: the same network evaluated in float64 by torch on the CPU (conv2d VALID on the once-padded image, ReLU,
 tf.nn.l2_normalize - model.py:51-64 of the reference as model.NET restates it).  The float32 library path (MIOpen) is
@@ -11,6 +11,8 @@ import os
 import numpy as np
 import pytest
 import torch
+
+import tolerances as tol
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
@@ -79,9 +81,12 @@ def test_split_features_as_close_to_float64_as_the_library_path(nets, H, W):
         e_lib = max(float((lib[i].double().cpu() - ref[i]).abs().max()) for i in range(2))
         e_spl = max(float((spl[i].double().cpu() - ref[i]).abs().max()) for i in range(2))
         record["%s %dx%d" % (name, W, H)] = {"library_fp32_max_abs_err": e_lib, "split_f16_max_abs_err": e_spl}
-        # unit vectors: absolute error = error relative to the vector norm.  Measured: library 3-5e-7, split 2-6e-7
-        assert e_spl <= 2e-6, "%s: split path %g from float64" % (name, e_spl)
-        assert e_spl <= max(3.0 * e_lib, 1e-6), "%s: split %g vs library %g" % (name, e_spl, e_lib)
+        # unit vectors: absolute error = error relative to the vector norm.  The SAME bound for both paths (round 4: the
+        # cross terms have an accumulator of their own; measured library 1.1e-7 .. 2.8e-7, split 1.3e-7 .. 3.1e-7;
+        # round 2's single accumulator: up to 5.3e-7)
+        assert e_spl <= tol.FEATURES_F32_CLASS_ABS, "%s: split path %g from float64" % (name, e_spl)
+        assert e_lib <= tol.FEATURES_F32_CLASS_ABS, "%s: library path %g from float64" % (name, e_lib)
+        assert e_spl <= 1.5 * e_lib + 5e-8, "%s: split %g vs library %g" % (name, e_spl, e_lib)
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     path = os.path.join(out, "parity_features_split.json")
@@ -104,6 +109,23 @@ def test_split_features_golden(pf, golden_cases, net_layers):
         fl, fr = net.features_pair_hwc_split(left, right)
         assert np.abs(fl.cpu().numpy() - g["fl"]).max() <= 1e-5, name
         assert np.abs(fr.cpu().numpy() - g["fr"]).max() <= 1e-5, name
+
+
+def test_saturation_is_reported_by_the_kernels(nets, pf):
+    """An activation beyond the f16 range of the stored records (|x| >= 255.9) sets the device flag the kernels carry
+    (no host-side guess): ordinary standardised images never do, an image scaled by 1e4 does, the flag resets on read,
+    and process_functional.compute_features then answers with the float32 library path."""
+    net = nets["converted reference checkpoint"]
+    L, R = smooth_pair(40, 56, 5)
+    net.features_pair_hwc_split(L.cuda(), R.cuda())
+    assert net.split_saturated() is False
+    big = (L * 1e4).cuda()
+    net.features_pair_hwc_split(big, R.cuda())
+    assert net.split_saturated() is True and net.split_saturated() is False
+    fl, fr = pf.compute_features(big[:, :, None].cpu().numpy(), R[:, :, None].numpy(), 11, 11, net)
+    lib = net.features_pair_hwc(big, R.cuda())
+    assert np.array_equal(fl, lib[0].cpu().numpy()) or np.abs(fl - lib[0].cpu().numpy()).max() <= 1e-6
+    assert net.split_saturated() is False                       # compute_features consumed the flag
 
 
 def test_split_weights_follow_weight_updates(nets):

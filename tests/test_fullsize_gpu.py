@@ -186,7 +186,7 @@ def test_benchmarked_path_against_bit_exact_variant_full_size(net_layers, cfg):
     # the stated tolerance of the fast variants (src/tolerances.py; the same constants at every configuration).
     # Round 3 measured: 0 flips at cfg2, 2 of 931 500 at cfg3, 96 of 3 000 000 at cfg4; 98.7-99.5 % within 1e-3 px
     bad = tol.fast_violations(a.size, int((kf["wta"][0] != ke["wta"][0]).sum()), int((kf["wta"][1] != ke["wta"][1]).sum()),
-                              close, float(np.percentile(np.abs(np.where(fin, a - b, np.inf)), 99.9)))
+                              close, float(np.percentile(np.abs(np.where(fin, a - b, np.inf)), 99.0)))
     assert not bad, "%s: %s" % (cfg, "; ".join(bad))
 
 

@@ -165,7 +165,9 @@ def test_read_gray_matches_libpng_fixture():
 def test_drop_in_defaults_are_the_bit_exact_variants():
     import match
     import process_functional as pf
-    assert pf.COST_VOLUME_MODE == "exact" and pf.CBCA_ORDER == "reference"
+    assert pf.COST_VOLUME_MODE == "exact" and pf.CBCA_ORDER == "reference" and pf.FEATURES == "split_f16"
+    assert match.parser.parse_args(["--list_file", "l", "--data_dir", "d", "--save_dir", "s", "-t", "x", "-s", "0", "-e",
+                                    "3"]).features is None          # None = the hand-written kernels where they apply
     base = ["--list_file", "l", "--data_dir", "d", "--save_dir", "s", "-t", "x", "-s", "0", "-e", "3"]
     assert match.parser.parse_args(base).fast is False
     assert match.parser.parse_args(base + ["--fast"]).fast is True
@@ -232,9 +234,9 @@ def test_gpu_flag_pins_the_card_only_when_given(monkeypatch):
 
 def test_stated_tolerance_helper():
     import tolerances as tol
-    assert tol.fast_violations(750000, 0, 0, 0.99, 0.05) == []
-    assert len(tol.fast_violations(750000, 76, 0, 0.97, 0.3)) == 3
-    assert tol.fast_violations(3000000, 96, 96, 0.988, 0.1) == []      # round 3's cfg4 numbers are inside the statement
+    assert tol.fast_violations(750000, 0, 0, 0.99, 0.005) == []
+    assert len(tol.fast_violations(750000, 76, 0, 0.97, 0.03)) == 3
+    assert tol.fast_violations(1500000, 98, 0, 0.9875, 0.0015) == []   # round 4's cfg4 numbers are inside the statement
 
 
 def test_synthetic_pairs_are_deterministic_and_standardised():
