@@ -87,7 +87,8 @@ def test_cfg1_whole_pair_stage_by_stage(net_layers):
     m = sd.StereoMatcher(net, cv_mode=hip.MCCNN_CV_EXACT, cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER)
     keep = {}
     exact_map = m.match(dev(L), dev(R), D, keep=keep).cpu().numpy()
-    fl = net.features_pair_hwc(dev(L[:, :, 0]), dev(R[:, :, 0]))
+    assert m.features == "split_f16"          # the default: the hand-written conv stack (deterministic, no library)
+    fl = net.features_pair_hwc_split(dev(L[:, :, 0]), dev(R[:, :, 0]))
     ocv = o.compute_cost_volume(fl[0].cpu().numpy(), fl[1].cpu().numpy(), D)
     assert_bits(keep["cv"][0].cpu().numpy(), ocv[0], "cfg1 cost volume L")
     assert_bits(keep["cv"][1].cpu().numpy(), ocv[1], "cfg1 cost volume R")

@@ -103,6 +103,9 @@ def main():
     fl = torch.nn.functional.normalize(torch.randn((H, W, 64), device="cuda", generator=g), dim=-1).contiguous()
     fr = torch.nn.functional.normalize(torch.randn((H, W, 64), device="cuda", generator=g), dim=-1).contiguous()
     add("cost_volume_exact", lambda: sd.cost_volume(fl, fr, D, hip.MCCNN_CV_EXACT, out=(va, vb)), 2 * vol_bytes)
+    if D <= 512:
+        hl, hr = (torch.zeros((H, W, sd.hwd_pitch(D)), device="cuda") for _ in range(2))
+        add("cost_volume_hwd", lambda: sd.cost_volume_hwd(fl, fr, D, out=(hl, hr)), 2 * vol_bytes)
     add("cost_volume_mfma", lambda: sd.cost_volume(fl, fr, D, hip.MCCNN_CV_MFMA, out=(va, vb)), 2 * vol_bytes)
 
     # feature stack: both views; "bytes" = the activations each of the four 64 -> 64 layers reads and writes once
