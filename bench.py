@@ -377,6 +377,7 @@ def main():
         "cbca_iter": 2 * vol_bytes,       # one iteration on one volume
         "cbca_iter_pair": 2 * 2 * vol_bytes,   # one iteration on BOTH volumes (one launch: left + right)
         "cbca_iter_hwd_pair": 2 * 2 * vol_bytes,   # the same, reference-order kernel on pixel-major volumes
+        "cbca_iter_prog_pair": 2 * 2 * vol_bytes,  # the same, program-driven assembly kernel (the default)
         "sgm_pass": 2 * 2 * vol_bytes,    # one direction on BOTH volumes (one launch advances left + right)
         "sgm_first_pass": 2 * 2 * vol_bytes,
     }

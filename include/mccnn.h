@@ -45,7 +45,7 @@ extern "C" {
 
 typedef void *mccnn_stream_t; /* hipStream_t */
 
-#define MCCNN_ABI_VERSION 3 /* 2: window-mask plane in the support buffer, *_hwd entry points; 3: saturation flags */
+#define MCCNN_ABI_VERSION 4 /* 2: window-mask plane, *_hwd entry points; 3: saturation flags; 4: program-driven CBCA */
 
 #define MCCNN_E_INVALID (-1)     /* bad argument (null pointer, non-positive size, unsupported shape) */
 #define MCCNN_E_UNSUPPORTED (-2) /* shape outside what the kernels were built for (e.g. D > 512 for SGM) */
@@ -165,6 +165,23 @@ int mccnn_cbca_iter_hwd_pair_wta(const float *in_left, float *out_left, const mc
                                  const float *in_right, float *out_right, const mccnn_support_t *support_right, int D,
                                  int H, int W, int L, float *disparity_left, float *disparity_right, int store_right,
                                  mccnn_stream_t stream);
+
+/* ---- a4 on the pixel-major layout, program-driven (pf:149-163; round 4) ---------------------------------------------
+ * Bit-identical to mccnn_cbca_iter_hwd_pair and faster (0.45 vs 0.55 ms per two-volume iteration at 750x500x256): the
+ * per-image control of that kernel - region rows, pixel windows and arm runs of every 4 x 5 patch of anchors - is
+ * compiled once per image into a linear program per patch (mccnn_cbca_prog_build_pair, after mccnn_cross_arms), and the
+ * iteration is an interpreter of those programs written in gfx950 assembly (csrc/asm/cbca_prog_gen.py).  The programs
+ * depend on the image, on D (disparities per lane) and on nothing else: one build serves all 18 iterations of a pair.
+ *   mccnn_cbca_prog_bytes: size of ONE image's program buffer; 0 when the shape is outside what the programs encode
+ *     (W > 2180 columns, or volumes beyond a buffer descriptor's reach) - callers then stay with mccnn_cbca_iter_hwd_pair.
+ *   support_*: the whole buffers mccnn_cross_arms wrote (plane 0 is read).  L <= 14; outputs must not alias inputs. */
+size_t mccnn_cbca_prog_bytes(int D, int H, int W);
+int mccnn_cbca_prog_build_pair(const mccnn_support_t *support_left, const mccnn_support_t *support_right, int D, int H,
+                               int W, int L, void *prog_left, void *prog_right, mccnn_stream_t stream);
+int mccnn_cbca_iter_prog_pair(const float *in_left, float *out_left, const mccnn_support_t *support_left,
+                              const void *prog_left, const float *in_right, float *out_right,
+                              const mccnn_support_t *support_right, const void *prog_right, int D, int H, int W, int L,
+                              mccnn_stream_t stream);
 
 /* ---- layout changes between DHW and HWD ------------------------------------------------------------------- */
 int mccnn_hwd_pitch(int D); /* Dp: D rounded up to a multiple of 4 (16-byte rows) */

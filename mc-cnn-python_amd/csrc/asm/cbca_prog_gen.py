@@ -83,7 +83,7 @@ SOPP = {"s_waitcnt", "s_branch", "s_cbranch_scc0", "s_cbranch_scc1", "s_cbranch_
         "s_endpgm", "s_set_gpr_idx_off", "s_barrier", "s_cbranch_execz"}
 SOPK = {"s_movk_i32"}
 SMEM = {"s_load_dword", "s_load_dwordx2", "s_load_dwordx4", "s_load_dwordx8", "s_load_dwordx16"}
-VOP3 = {"v_readlane_b32", "v_fma_f32", "v_div_scale_f32", "v_div_fmas_f32", "v_div_fixup_f32", "v_mul_lo_u32",
+VOP3 = {"v_pk_add_f32", "v_readlane_b32", "v_fma_f32", "v_div_scale_f32", "v_div_fmas_f32", "v_div_fixup_f32", "v_mul_lo_u32",
         "v_mad_u32_u24", "v_cndmask_b32_e64", "v_cmp_lt_f32_e64", "v_cmp_eq_f32_e64", "v_cmp_gt_u32_e64",
         "v_min3_f32", "v_lshl_add_u32"}
 MUBUF = {"buffer_load_dword", "buffer_load_dwordx2", "buffer_load_dwordx3", "buffer_load_dwordx4",
@@ -116,7 +116,8 @@ def ins_size(i):
 
 class Params:
     def __init__(self, vpl=4, K=2, G=5, W=12, NB=1, PF=0, wta=False, debug=0):
-        assert K == 2, "anchor-set lines are written for K = 2"
+        assert K in (1, 2, 4, 8), "anchor sets are aligned power-of-two groups of anchor rows"
+        assert K * G <= 20, "the region sizes of the K x G anchors live in s[16:35]"
         self.VPL, self.K, self.G, self.W, self.NB, self.PF, self.wta, self.debug = vpl, K, G, W, NB, PF, wta, debug
         self.MAXD = min(W, R + 1)                   # longest descending run one op can carry (self + left arm)
         self.MAXA = min(W, R)                       # longest ascending run
@@ -132,6 +133,14 @@ class Params:
     def acc(self, k, j, c=0):
         return (k * self.G + j) * self.RS + c
 
+    def sets(self):
+        """Anchor-row sets an ADD line exists for: aligned groups of 1, 2, 4 .. K rows (bit k = anchor row k)."""
+        out, s = [], 1
+        while s <= self.K:
+            out += [((1 << s) - 1) << st for st in range(0, self.K, s)]
+            s *= 2
+        return out
+
     def name(self):
         return "mccnn_cbca_prog_v%d%s" % (self.VPL, "_wta" if self.wta else "")
 
@@ -140,13 +149,11 @@ class Params:
 S = dict(
     karg=0,            # s[0:1] kernarg segment
     bx=2, by=3, bz=4,  # workgroup ids
-    # kernarg block 0 (0x00..0x3f): in0 in1 out0 out1 prog0 prog1 sup0 sup1
-    ka=8,              # s[8:23]
     # kernarg block 1 (0x40..0x5f): Dp H W nchunks band_rows band_groups prog_stride_bytes ngroups
-    Dp=24, H=25, W=26, nchunks=27, band_rows=28, band_groups=29, prog_stride=30, ngroups=31,
-    # kernarg block 2 (0x60..0x7f): disp0 disp1 (wta) D store1 pad pad
-    disp=32,           # s[32:35]
-    D=36, store1=37,
+    Dp=8, H=9, W=10, nchunks=11, band_rows=12, band_groups=13, prog_stride=14, ngroups=15,
+    # kernarg block 0 (0x00..0x3f): in0 in1 out0 out1 prog0 prog1 sup0 sup1 - dead once the job's pointers are picked
+    ka=16,             # s[16:31]
+    cnt=16,            # s[16 : 16 + K*G] in the END handler: region sizes of the anchors (K*G <= 20)
     y0=40, x0=41, job=42, chunk=43,
     inp=44,            # s[44:45]
     outp=46,           # s[46:47]
@@ -160,12 +167,27 @@ S = dict(
     safe_m0=70, progoff=71,
     t0=72, t1=73, t2=74, t3=75, t4=76, t5=77,
     rs_out=80,         # s[80:83]
-    cnt=84,            # s[84 : 84 + K*G]
+    # kernarg block 2 (0x60..0x7f, WTA kernel): disp0 disp1 D store1
+    disp=84,           # s[84:87]
+    D=88, store1=89,
     dispp=96,          # s[96:97]
     dump=98, pfoff=99,
     pfa=100,           # s[100:101]
 )
 NSGPR = 102
+
+
+def decompose(aset, K):
+    """An arbitrary set of anchor rows as the aligned power-of-two groups the kernel has lines for, largest first."""
+    out, s = [], K
+    while s >= 1 and aset:
+        for st in range(0, K, s):
+            m = ((1 << s) - 1) << st
+            if aset & m == m:
+                out.append(m)
+                aset &= ~m
+        s //= 2
+    return out
 
 
 def sreg(n, cnt=1):
@@ -301,7 +323,7 @@ class Gen:
         # ---- ADD lines: (column j, anchor set 1 = row 0 / 2 = row 1 / 3 = both, direction) ---------------------------
         self.lines = {}
         for j in range(G):
-            for aset in (1, 2, 3):
+            for aset in P.sets():
                 for d, maxn in (("d", P.MAXD), ("a", P.MAXA)):
                     name = "add_j%d_s%d_%s" % (j, aset, d)
                     self.label(name)
@@ -311,7 +333,15 @@ class Gen:
                         slot = (blk - 1) if d == "d" else (1 - blk)
                         for k in range(K):
                             if aset & (1 << k):
-                                for c in range(VPL):
+                                # packed adds: in VGPR index mode a v_add_f32 issues at half rate (4.3 clocks per wave
+                                # instruction against 2.4 without; profiles/r04_probe_gpridx_rate.txt), a
+                                # v_pk_add_f32 at its full 4.7 for two adds - the same IEEE sums either way
+                                c = 0
+                                while c + 1 < VPL:
+                                    e("v_pk_add_f32", vreg(P.acc(k, j, c), 2), vreg(P.acc(k, j, c), 2),
+                                      vreg(P.PHYS_WIN + P.RS * slot + c, 2))
+                                    c += 2
+                                if c < VPL:
                                     e("v_add_f32", vreg(P.acc(k, j, c)), vreg(P.acc(k, j, c)),
                                       vreg(P.PHYS_WIN + P.RS * slot + c))
                     self.tail()
@@ -519,13 +549,20 @@ def header(L, P):
         out.append("#define %s%s %d" % (pre, k, L[k]))
     out.append("#define %sREFILL %d" % (pre, L["refill"]))
     out.append("#define %sEND %d" % (pre, L["end"]))
-    # add[j][aset-1][dir] = offset of the line's first block
+    # add[j][aset][dir] = offset of the line's first block (-1: no line for that set, see decompose())
     rows = []
     for j in range(P.G):
-        rows.append("{" + ", ".join("{%d, %d}" % (L["add"][(j, a, "d")], L["add"][(j, a, "a")]) for a in (1, 2, 3)) + "}")
+        cells = []
+        for a in range(1 << P.K):
+            cells.append("{%d, %d}" % ((L["add"][(j, a, "d")], L["add"][(j, a, "a")]) if (j, a, "d") in L["add"] else (-1, -1)))
+        rows.append("{" + ", ".join(cells) + "}")
     out.append("#define %sADD_INIT {%s}" % (pre, ", ".join(rows)))
     out.append("#define %sLOAD_INIT {%s}" % (pre, ", ".join("{" + ", ".join(str(x) for x in row) + "}" for row in L["load"])))
+    out.append("#define %sLOAD0_INIT {%s}" % (pre, ", ".join(str(x) for x in L["load"][0])))
     out.append("#define %sWAIT_INIT {%s}" % (pre, ", ".join(str(x) for x in L["wait"])))
+    # a mccnn::prog::Layout (csrc/cbca_prog_build.h) for this kernel
+    out.append("#define %sLAYOUT {%sVPL, %sRS, %sK, %sG, %sW, %sMAXD, %sMAXA, %sBLK, %sM0_SRC1, %sREFILL, %sEND, "
+               "%sADD_INIT, %sLOAD0_INIT}" % ((pre,) * 14))
     return "\n".join(out) + "\n"
 
 
@@ -533,13 +570,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--vpl", type=int, default=4)
     ap.add_argument("--w", type=int, default=12)
+    ap.add_argument("--k", type=int, default=2)
     ap.add_argument("--nb", type=int, default=1)
     ap.add_argument("--pf", type=int, default=0)
     ap.add_argument("--wta", action="store_true")
     ap.add_argument("-o", default=None)
     ap.add_argument("--header", default=None)
     a = ap.parse_args()
-    P = Params(vpl=a.vpl, W=a.w, NB=a.nb, PF=a.pf, wta=a.wta)
+    P = Params(vpl=a.vpl, K=a.k, W=a.w, NB=a.nb, PF=a.pf, wta=a.wta)
     g = Gen(P).build()
     if a.o:
         open(a.o, "w").write(g.render())

@@ -324,6 +324,50 @@ def cbca_hwd_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, D, iteration
     return (sl, dl), (sr, dr)
 
 
+def cbca_prog_buffers(D, H, W, device):
+    """Two program buffers (left, right image) for cbca_prog_pair, or None when the shape is outside what the
+    program-driven kernels encode (mccnn_cbca_prog_bytes == 0): the caller then stays with cbca_hwd_pair."""
+    n = int(hip.load().mccnn_cbca_prog_bytes(int(D), int(H), int(W)))
+    if n == 0:
+        return None
+    return (torch.empty((n // 4,), dtype=torch.int32, device=device), torch.empty((n // 4,), dtype=torch.int32, device=device))
+
+
+def cbca_prog_build_pair(support_l, support_r, D, distance_threshold, progs):
+    """Compiles both images' support regions into the per-patch programs of the assembly aggregation kernel
+    (mccnn_cbca_prog_build_pair): once per pair, after cross_arms_pair, for all iterations."""
+    H, W = support_l.shape
+    _check_support(support_l, H, W, "cbca_prog_build_pair")
+    _check_support(support_r, H, W, "cbca_prog_build_pair")
+    hip.check(hip.load().mccnn_cbca_prog_build_pair(hip.ptr(support_l), hip.ptr(support_r), int(D), H, W,
+                                                    int(distance_threshold), hip.ptr(progs[0]), hip.ptr(progs[1]),
+                                                    hip.stream()), "mccnn_cbca_prog_build_pair")
+    return progs
+
+
+def cbca_prog_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, progs, D, iterations, distance_threshold, timer=None):
+    """cbca_hwd_pair's result (bit for bit) through the program-driven assembly kernel (mccnn_cbca_iter_prog_pair);
+    `progs` from cbca_prog_build_pair on the same support buffers and D.  Same ping-pong contract."""
+    H, W, Dp = vol_l.shape
+    assert Dp == hwd_pitch(D)
+    for t in (tmp_l, vol_r, tmp_r):
+        if tuple(t.shape) != (H, W, Dp):
+            raise ValueError("cbca_prog_pair: the volumes must have the same shape")
+    _check_support(support_l, H, W, "cbca_prog_pair")
+    _check_support(support_r, H, W, "cbca_prog_pair")
+    lib = hip.load()
+    (sl, dl), (sr, dr) = (vol_l, tmp_l), (vol_r, tmp_r)
+    timer = timer or _NO_TIMER
+    for _ in range(int(iterations)):
+        timer.start("cbca_iter_prog_pair")
+        hip.check(lib.mccnn_cbca_iter_prog_pair(hip.ptr(sl), hip.ptr(dl), hip.ptr(support_l), hip.ptr(progs[0]), hip.ptr(sr),
+                                                hip.ptr(dr), hip.ptr(support_r), hip.ptr(progs[1]), int(D), H, W,
+                                                int(distance_threshold), hip.stream()), "mccnn_cbca_iter_prog_pair")
+        timer.stop()
+        sl, dl, sr, dr = dl, sl, dr, sr
+    return (sl, dl), (sr, dr)
+
+
 def cbca_both_views(vol, tmp, support_self, support_other, iterations, distance_threshold, side, timer=None):
     """`iterations` rounds of cross-based averaging with the paper's two-view support regions (opt-in extra, see
     mccnn_cbca_iter_both): arms intersected with the other view's at the partner pixel x -/+ d.  Same ping-pong
@@ -556,7 +600,7 @@ class StereoMatcher(object):
     """
 
     def __init__(self, net, hp=None, cv_mode=hip.MCCNN_CV_EXACT, cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER,
-                 feature_tile_rows=None, extras=None, features="auto", layout="auto"):
+                 feature_tile_rows=None, extras=None, features="auto", layout="auto", cbca_kernel="auto"):
         self.device = hip.require_device()
         self.net = net
         self.hp = dict(DEFAULT_HP)
@@ -581,6 +625,11 @@ class StereoMatcher(object):
         if layout not in ("auto", "plane_major"):
             raise ValueError("layout must be 'auto' or 'plane_major'")
         self.layout = layout
+        # reference-order aggregation on pixel-major volumes: "prog" = the program-driven assembly kernel
+        # (mccnn_cbca_iter_prog_pair), "hwd" = cbca_hwd_kernel; "auto": the first wherever its programs encode the shape
+        if cbca_kernel not in ("auto", "prog", "hwd"):
+            raise ValueError("cbca_kernel must be 'auto', 'prog' or 'hwd'")
+        self.cbca_kernel = cbca_kernel
         # opt-in departures from the reference (they change the output): the paper's rules it leaves out, and the
         # scalar promotion of the NumPy it was written for
         self.extras = dict(both_view_support=False, interpolation_directions=4, occlusion_from_left=False,
@@ -612,6 +661,11 @@ class StereoMatcher(object):
                 status=torch.empty((H, W), dtype=torch.int32, device=dev),
                 maps=torch.empty((6, H, W), dtype=torch.float32, device=dev),   # dl, dr, interp, subpixel, median, out
             )
+            ws["progs"] = None
+            if self.pixel_major() and self.cbca_kernel != "hwd":
+                ws["progs"] = cbca_prog_buffers(D, H, W, dev)
+                if ws["progs"] is None and self.cbca_kernel == "prog":
+                    raise ValueError("cbca_kernel='prog': %dx%dx%d is outside what the aggregation programs encode" % (W, H, D))
             bilateral_table_device(5, 5, 0, self.hp["blur_sigma"], dev)
             self._ws = {key: ws}  # one shape resident at a time
             self._graphs = {}
@@ -655,6 +709,8 @@ class StereoMatcher(object):
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
                 sup_l, sup_r = cross_arms_pair(L, R, hp["cbca_intensity"], hp["cbca_distance"], ws["sup_l"], ws["sup_r"])
+                if ws["progs"] is not None:
+                    cbca_prog_build_pair(sup_l, sup_r, D, hp["cbca_distance"], ws["progs"])
 
         timer.start("features")
         if self.features == "split_f16":
@@ -681,6 +737,10 @@ class StereoMatcher(object):
             timer.start("cross_arms")
             sup_l, sup_r = cross_arms_pair(L, R, hp["cbca_intensity"], hp["cbca_distance"], ws["sup_l"], ws["sup_r"])
             timer.stop()
+            if ws["progs"] is not None:
+                timer.start("cbca_prog_build")
+                cbca_prog_build_pair(sup_l, sup_r, D, hp["cbca_distance"], ws["progs"])
+                timer.stop()
 
         ex = self.extras
         m = ws["maps"] if keep is None else torch.empty_like(ws["maps"])
@@ -690,8 +750,22 @@ class StereoMatcher(object):
                 timer.start("cv_to_pixel_major")
                 lh, rh = dhw_to_hwd(lcv, as_hwd(b2)), dhw_to_hwd(rcv, as_hwd(b3))
                 timer.stop()
-            (lh, lt), (rh, rt) = cbca_hwd_pair(lh, as_hwd(b0), sup_l, rh, as_hwd(b1), sup_r, D,
-                                               hp["cbca_num_iterations1"], hp["cbca_distance"], timer)
+            progs = ws["progs"]
+
+            def aggregate_hwd(lh, lt, rh, rt, n, **kw):
+                # the program-driven assembly kernel where its programs exist; an iteration that also carries the WTA
+                # is cbca_hwd_kernel's (same bits either way)
+                n = int(n)
+                tail = 1 if (kw.get("wta_out") is not None and n >= 1) else 0
+                if progs is None:
+                    return cbca_hwd_pair(lh, lt, sup_l, rh, rt, sup_r, D, n, hp["cbca_distance"], timer, **kw)
+                (lh, lt), (rh, rt) = cbca_prog_pair(lh, lt, sup_l, rh, rt, sup_r, progs, D, n - tail, hp["cbca_distance"],
+                                                    timer)
+                if tail:
+                    return cbca_hwd_pair(lh, lt, sup_l, rh, rt, sup_r, D, 1, hp["cbca_distance"], timer, **kw)
+                return (lh, lt), (rh, rt)
+
+            (lh, lt), (rh, rt) = aggregate_hwd(lh, as_hwd(b0), rh, as_hwd(b1), hp["cbca_num_iterations1"])
             if keep is not None:
                 keep["cbca1"] = (hwd_to_dhw(lh, D), hwd_to_dhw(rh, D))
             sgm_average_hwd(L, R, [lh, rh], sides, D, hp["sgm_P1"], hp["sgm_P2"], hp["sgm_Q1"], hp["sgm_Q2"],
@@ -701,9 +775,8 @@ class StereoMatcher(object):
             # the last iteration carries the WTA of both results (and leaves the right volume, which nothing else
             # reads, unwritten) when a wave holds all disparities of a pixel
             fuse = int(hp["cbca_num_iterations2"]) >= 1 and D <= cbca_hwd_wta_max_d()
-            (lh, lt), (rh, rt) = cbca_hwd_pair(lh, lt, sup_l, rh, rt, sup_r, D, hp["cbca_num_iterations2"],
-                                               hp["cbca_distance"], timer, wta_out=(m[0], m[1]) if fuse else None,
-                                               store_right=keep is not None)
+            (lh, lt), (rh, rt) = aggregate_hwd(lh, lt, rh, rt, hp["cbca_num_iterations2"],
+                                               wta_out=(m[0], m[1]) if fuse else None, store_right=keep is not None)
             if keep is not None:
                 keep["cbca2"] = (hwd_to_dhw(lh, D), hwd_to_dhw(rh, D))
             if fuse:

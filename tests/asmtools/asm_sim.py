@@ -384,6 +384,20 @@ class Wave:
                     with np.errstate(all="ignore"):
                         r = f32(self.rv(a[1], 0)) + f32(self.rv(a[2], 1))
                     self.wv(a[0], r.astype(np.float32).view(np.uint32))
+                elif op == "v_pk_add_f32":
+                    d, s0, s1 = self.vrange(a[0]), self.vrange(a[1]), self.vrange(a[2])
+                    assert len(d) == len(s0) == len(s1) == 2 and d[0] % 2 == 0 and s0[0] % 2 == 0 and s1[0] % 2 == 0
+                    b0 = self._vidx(s0[0], 0)
+                    b1 = self._vidx(s1[0], 1)
+                    if b1 % 2:
+                        raise SimError("v_pk_add_f32: indexed source pair v%d is not even-aligned" % b1)
+                    res = []
+                    for c in range(2):
+                        self._check_ready(b0 + c), self._check_ready(b1 + c)
+                        with np.errstate(all="ignore"):
+                            res.append((f32(self.v[b0 + c]) + f32(self.v[b1 + c])).astype(np.float32).view(np.uint32))
+                    for c in range(2):
+                        self.wv("v%d" % (d[0] + c), res[c])
                 elif op == "v_cvt_f32_u32":
                     self.wv(a[0], self.rv(a[1], 0).astype(np.float32).view(np.uint32))
                 elif op == "v_readlane_b32":

@@ -10,6 +10,19 @@ import numpy as np
 R = 13
 
 
+def decompose(aset, K):
+    """= cbca_prog_gen.decompose: a set of anchor rows as aligned power-of-two groups, largest first."""
+    out, s = [], K
+    while s >= 1 and aset:
+        for st in range(0, K, s):
+            m = ((1 << s) - 1) << st
+            if aset & m == m:
+                out.append(m)
+                aset &= ~m
+        s //= 2
+    return out
+
+
 def arms_of(word):
     w = int(word)
     return w & 31, (w >> 5) & 31, (w >> 10) & 31, (w >> 15) & 31     # up, down, left, right
@@ -21,13 +34,12 @@ def band_rows_of(H, K):
 
 
 def prog_stride_dwords(L):
-    """Upper bound of a patch's program: per region row at most ceil(NW / W) + G windows with a LOAD + WAIT each and
-    2 G K arm ops (+ as many again for split arms), one REFILL per 63 ops, END; rounded to whole 64-op chunks."""
+    """= mccnn::prog::stride_dwords (csrc/cbca_prog_build.h): upper bound of a patch's program in dwords."""
     K, G, W = L["K"], L["G"], L["W"]
     rows = 2 * K + 2 * R - 1
-    nw = G + 2 * R
-    per_row = 2 * (-(-nw // W) + 2 * G) + 4 * G * K
-    n = rows * per_row + 2
+    groups = K // 2 if K >= 2 else 1
+    pieces = -(-(R + 1) // W)
+    n = rows * pieces * (2 * G + 2 * G * groups) + 2
     n += n // 63 + 1
     return -(-n // 64) * 64
 
@@ -163,15 +175,16 @@ def build_program(sup0, H, W, y0, x0, L):
     def arms(i):
         lo, hi, p, runs = units[i]
         wb = (i % NB) * WW                                             # first physical slot of this unit's window
-        for d, j, aset, first, n in runs:
-            nk = bin(aset).count("1")
+        for d, j, aset_all, first, n in runs:
             sf = first - lo
-            if d == "d":
-                assert 1 <= n <= MAXD and 0 <= sf - n + 1 and sf < WW
-                emit((L["add"][(j, aset, "d")] + (MAXD - n) * BLK * nk) | ((M0 | (RS * (wb + sf - n + 1))) << 16))
-            else:
-                assert 1 <= n <= MAXA and 0 <= sf and sf + n - 1 < WW
-                emit((L["add"][(j, aset, "a")] + (MAXA - n) * BLK * nk) | ((M0 | (RS * (wb + sf + n - 1))) << 16))
+            for aset in decompose(aset_all, L["K"]):                   # aligned groups of anchor rows the kernel has lines for
+                nk = bin(aset).count("1")
+                if d == "d":
+                    assert 1 <= n <= MAXD and 0 <= sf - n + 1 and sf < WW
+                    emit((L["add"][(j, aset, "d")] + (MAXD - n) * BLK * nk) | ((M0 | (RS * (wb + sf - n + 1))) << 16))
+                else:
+                    assert 1 <= n <= MAXA and 0 <= sf and sf + n - 1 < WW
+                    emit((L["add"][(j, aset, "a")] + (MAXA - n) * BLK * nk) | ((M0 | (RS * (wb + sf + n - 1))) << 16))
 
     if NB == 1:
         for i in range(len(units)):

@@ -44,11 +44,12 @@ def oracle_cbca(img, vol):
     return out
 
 
-@pytest.mark.parametrize("vpl,w,nb", [(4, 12, 1), (3, 12, 1), (2, 12, 1), (4, 8, 1), (4, 10, 2)])
-def test_size_model_matches_the_assembler(tmp_path, vpl, w, nb):
+@pytest.mark.parametrize("vpl,w,nb,k", [(4, 12, 1, 2), (3, 12, 1, 2), (2, 12, 1, 2), (4, 8, 1, 2), (4, 10, 2, 2), (4, 20, 1, 4),
+                                         (2, 16, 1, 4)])
+def test_size_model_matches_the_assembler(tmp_path, vpl, w, nb, k):
     if not os.path.exists(os.path.join(LLVM, "clang")):
         pytest.skip("no ROCm assembler")
-    g = gen.Gen(gen.Params(vpl=vpl, W=w, NB=nb)).build()
+    g = gen.Gen(gen.Params(vpl=vpl, K=k, W=w, NB=nb)).build()
     s = tmp_path / "k.s"
     s.write_text(g.render())
     obj = tmp_path / "k.o"
@@ -68,9 +69,9 @@ def test_size_model_matches_the_assembler(tmp_path, vpl, w, nb):
 
 @pytest.mark.parametrize("H,W,D,seed,flat", [(12, 17, 8, 0, False), (30, 41, 5, 1, False), (9, 33, 4, 2, True),
                                                (40, 48, 6, 3, False)])
-@pytest.mark.parametrize("w,nb", [(12, 1), (8, 1), (10, 2), (6, 2)])
-def test_programs_reproduce_the_oracle_op_level(H, W, D, seed, flat, w, nb):
-    L = gen.Gen(gen.Params(vpl=4, W=w, NB=nb)).build().layout()
+@pytest.mark.parametrize("w,nb,k", [(12, 1, 2), (8, 1, 2), (10, 2, 2), (6, 2, 2), (20, 1, 4), (12, 1, 4), (16, 1, 1)])
+def test_programs_reproduce_the_oracle_op_level(H, W, D, seed, flat, w, nb, k):
+    L = gen.Gen(gen.Params(vpl=4, K=k, W=w, NB=nb)).build().layout()
     img, vol = make_case(H, W, D, seed, flat)
     sup0 = support_words(img)
     want = oracle_cbca(img, vol)
@@ -83,6 +84,37 @@ def test_programs_reproduce_the_oracle_op_level(H, W, D, seed, flat, w, nb):
             for (y, x), q in ref.run_program(prog, hwd, H, W, y0, x0, L, sup0).items():
                 got[y, x] = q
     assert np.array_equal(got.transpose(2, 0, 1), want)
+
+
+@pytest.mark.parametrize("vpl,k,w", [(4, 4, 20), (4, 2, 12), (3, 4, 20), (2, 4, 20), (4, 4, 9), (4, 1, 16)])
+def test_cxx_builder_equals_the_python_statement(tmp_path, vpl, k, w):
+    """csrc/cbca_prog_build.h (what the device kernel runs per patch), compiled for the host, against
+    tests/asmtools/cbca_prog_ref.py: the same ops, word for word, on textured, flat and tiny images."""
+    import ctypes
+    P = gen.Params(vpl=vpl, K=k, W=w)
+    g = gen.Gen(P).build()
+    L = g.layout()
+    (tmp_path / "layout.h").write_text(gen.header(L, P) + "#define TEST_LAYOUT CBCA_PROG_V%d_LAYOUT\n" % vpl)
+    so = tmp_path / "libprog.so"
+    subprocess.check_call(["g++", "-O1", "-shared", "-fPIC", "-std=c++17",
+                           "-I" + os.path.join(ROOT, "mc-cnn-python_amd", "csrc"), "-I" + str(tmp_path),
+                           os.path.join(ROOT, "tests", "asmtools", "prog_build_host.cpp"), "-o", str(so)])
+    lib = ctypes.CDLL(str(so))
+    assert lib.prog_stride_dwords() == ref.prog_stride_dwords(L)
+    cap = lib.prog_stride_dwords()
+    u32p = ctypes.POINTER(ctypes.c_uint32)
+    for (H, W, seed, flat) in ((12, 17, 0, False), (30, 41, 1, False), (9, 33, 2, True), (40, 48, 3, False), (3, 4, 4, False),
+                               (31, 64, 5, True)):
+        img, _ = make_case(H, W, 4, seed, flat)
+        sup0 = np.ascontiguousarray(support_words(img))
+        assert lib.prog_band_rows(H) == ref.band_rows_of(H, k)
+        for y0 in range(0, H, k):
+            for x0 in range(0, W, L["G"]):
+                want = ref.build_program(sup0, H, W, y0, x0, L)
+                got = np.zeros(cap, np.uint32)
+                n = lib.prog_build_patch(sup0.ctypes.data_as(u32p), H, W, y0, x0, got.ctypes.data_as(u32p), cap)
+                assert n == len(want) <= cap, (H, W, y0, x0, n, len(want))
+                assert np.array_equal(got[:n], want), (H, W, y0, x0)
 
 
 def simulate(g, L, img, vol, code_addr=0x7e00fffff000):
@@ -127,8 +159,9 @@ def simulate(g, L, img, vol, code_addr=0x7e00fffff000):
                                                        (4, 8, 1, 13, 21, 5, 6, True), (4, 12, 1, 7, 12, 300, 7, False),
                                                        (4, 10, 2, 12, 17, 8, 0, False), (4, 6, 2, 9, 33, 4, 2, True),
                                                        (3, 10, 2, 14, 23, 6, 4, False)])
-def test_generated_kernel_reproduces_the_oracle_in_the_simulator(vpl, w, nb, H, W, D, seed, flat):
-    g = gen.Gen(gen.Params(vpl=vpl, W=w, NB=nb)).build()
+@pytest.mark.parametrize("k", [2, 4])
+def test_generated_kernel_reproduces_the_oracle_in_the_simulator(vpl, w, nb, H, W, D, seed, flat, k):
+    g = gen.Gen(gen.Params(vpl=vpl, K=k, W=w, NB=nb)).build()
     L = g.layout()
     img, vol = make_case(H, W, D, seed, flat)
     got, st = simulate(g, L, img, vol)

@@ -95,6 +95,10 @@ def main():
         hb, hb2 = torch.empty_like(hwd), torch.empty_like(hwd2)
         add("cbca_iter_hwd", lambda: sd.cbca_hwd(hwd, hb, sup, D, 1, 14), 2 * vol_bytes)
         add("cbca_iter_hwd_pair", lambda: sd.cbca_hwd_pair(hwd, hb, sup, hwd2, hb2, sup2, D, 1, 14), 4 * vol_bytes)
+        progs = sd.cbca_prog_buffers(D, H, W, hwd.device)
+        if progs is not None:
+            add("cbca_prog_build", lambda: sd.cbca_prog_build_pair(sup, sup2, D, 14, progs), 0.0)
+            add("cbca_iter_prog_pair", lambda: sd.cbca_prog_pair(hwd, hb, sup, hwd2, hb2, sup2, progs, D, 1, 14), 4 * vol_bytes)
         add("wta_hwd", lambda: sd.wta_hwd(hwd, D), vol_bytes)
         del hb, hb2
     add("dhw_to_hwd", lambda: sd.dhw_to_hwd(va, hwd), 2 * vol_bytes)

@@ -23,12 +23,14 @@ import cbca_prog_ref as ref
 from bench import CONFIGS
 
 LLVM = "/opt/rocm/lib/llvm/bin"
+K_DEFAULT = 2
 
 
-def build_hsaco(vpl, w, outdir, nb=1, debug=0, pf=0):
+def build_hsaco(vpl, w, outdir, nb=1, debug=0, pf=0, k=None):
+    k = k or K_DEFAULT
     os.makedirs(outdir, exist_ok=True)
-    g = gen.Gen(gen.Params(vpl=vpl, W=w, NB=nb, debug=debug, PF=pf)).build()
-    base = os.path.join(outdir, "cbca_prog_v%d_w%d_b%d_g%d_p%d" % (vpl, w, nb, debug, pf))
+    g = gen.Gen(gen.Params(vpl=vpl, K=k, W=w, NB=nb, debug=debug, PF=pf)).build()
+    base = os.path.join(outdir, "cbca_prog_v%d_k%d_w%d_b%d_g%d_p%d" % (vpl, k, w, nb, debug, pf))
     if not os.path.exists(base + ".hsaco") or os.path.getmtime(base + ".hsaco") < os.path.getmtime(gen.__file__):
         open(base + ".s", "w").write(g.render())
         subprocess.check_call([LLVM + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c",
@@ -118,7 +120,10 @@ def main():
     ap.add_argument("--w", type=int, default=12); ap.add_argument("--small-only", action="store_true")
     ap.add_argument("--nb", type=int, default=1); ap.add_argument("--skip-small", action="store_true")
     ap.add_argument("--experiments", action="store_true"); ap.add_argument("--pf", default="")
+    ap.add_argument("--k", type=int, default=2)
     args = ap.parse_args()
+    global K_DEFAULT
+    K_DEFAULT = args.k
     hip.require_device()
     allok = True
     for vpl in (() if args.skip_small else (4, 2, 3)):
@@ -164,7 +169,7 @@ def main():
     print("full size bit-exact vs cbca_hwd: left %s right %s" % (torch.equal(b, want_l), torch.equal(d, want_r)), flush=True)
     vb = 4.0 * H * W * D
     ms = timeit(lambda: mod.launch((8 * meta["band_groups"], meta["ngroups"], nchunks * 2), ka), args.iters)
-    print("W=%d NB=%d regs=%d" % (args.w, args.nb, g.P.nvgpr))
+    print("K=%d W=%d NB=%d regs=%d" % (g.P.K, args.w, args.nb, g.P.nvgpr))
     print("cbca_prog pair      %8.4f ms  %6.1f GB/s (%.1f%% of 8 TB/s)" % (ms, 4 * vb / ms / 1e6, 4 * vb / ms / 1e6 / 80), flush=True)
     for pf in [int(x) for x in args.pf.split(",") if x]:
         g2, path2 = build_hsaco(vpl, args.w, os.path.join(ROOT, "mc-cnn-python_amd", "build", "asm"), args.nb, 0, pf)
