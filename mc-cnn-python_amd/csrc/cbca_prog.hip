@@ -1,7 +1,7 @@
 // a4 cost_volume_aggregation in the reference's summation order (/root/reference/src/process_functional.py:149-163) on
 // pixel-major volumes, program-driven: the per-image control of cbca_hwd_kernel (cbca_hwd.hip) - which region rows a
 // K x G patch of anchors sweeps, which pixels each row needs, which arms each anchor adds - is compiled ONCE per image
-// into a linear program per patch (cbca_prog_build_kernel below, one thread per patch, csrc/cbca_prog_build.h), and
+// into a linear program per patch (cbca_prog_build_kernel below, one wave per patch, csrc/cbca_prog_build.h), and
 // the aggregation itself is a threaded-code interpreter written in gfx950 assembly (csrc/asm/cbca_prog_gen.py
 // generates it: VGPR index mode, computed entries into straight lines of v_pk_add_f32, no test or branch per region
 // element).  Same additions in the same order per (pixel, disparity) as the reference: bit-identical to
@@ -63,18 +63,98 @@ static int kernel_for(int vpl, hipFunction_t *fn)
     return 0;
 }
 
-// One thread per patch (row group, column group, image).
-__global__ __launch_bounds__(64) void cbca_prog_build_kernel(const Layout L, const uint32_t *__restrict__ sup0,
+constexpr int kStageOps = 32;     // ops one sweep step can have with the layouts this library is built with (checked)
+struct StageEmitter {
+    uint32_t *col;                // this lane's column of the staging area
+    int n;
+    __device__ __forceinline__ void op(uint32_t v)
+    {
+        if (n < kStageOps) col[n * 64] = v;
+        ++n;
+    }
+};
+
+// One wave per patch (column group, row group, image); lane t builds sweep step t (a patch has at most
+// 2 K + 2 R - 1 = 33) into an LDS staging column, a wave scan turns the lanes' op counts into positions, and the ops
+// go out (raw op i lives at dword i + i / 63, a REFILL closes every 64-op chunk).  (One thread per patch took
+// 0.91 ms per 750x500 pair: 600 waves of serial, divergent code.)
+__global__ __launch_bounds__(64) void cbca_prog_build_kernel(const Layout Larg, const uint32_t *__restrict__ sup0,
                                                              const uint32_t *__restrict__ sup1, uint32_t *__restrict__ prog0,
                                                              uint32_t *__restrict__ prog1, int H, int W, int ngroups,
-                                                             int nrowgroups, int stride)
+                                                             int stride)
 {
-    const int cg = blockIdx.x * 64 + threadIdx.x, rg = blockIdx.y, job = blockIdx.z;
-    if (cg >= ngroups || rg >= nrowgroups) return;
+    // the handler offsets are looked up with per-lane indices: from LDS (a copy of the kernel argument), not from the
+    // kernarg segment in memory (a dependent ~0.4 us load per op)
+    __shared__ Layout L;
+    const int lane = threadIdx.x, cg = blockIdx.x, rg = blockIdx.y, job = blockIdx.z;
+    {
+        const int *src = reinterpret_cast<const int *>(&Larg);
+        int *dst = reinterpret_cast<int *>(&L);
+        for (int i = lane; i < (int)(sizeof(Layout) / 4); i += 64) dst[i] = src[i];
+        __syncthreads();
+    }
     const int y0 = rg * L.K;
     if (y0 >= H) return;
+    const uint32_t *sup = job ? sup1 : sup0;
     uint32_t *out = (job ? prog1 : prog0) + ((size_t)rg * ngroups + cg) * stride;
-    build_patch(L, job ? sup1 : sup0, H, W, y0, cg * L.G, out, stride);
+    // the patch's anchors (the same for every lane) and the lanes' work arrays live in LDS, not in scratch memory
+    __shared__ Patch P;
+    __shared__ int tmp[5 * MAXG][64];
+    {   // patch_setup (cbca_prog_build.h) with one anchor per lane: 20 independent loads instead of 20 in a row
+        const int K = L.K, G = L.G, x0 = cg * L.G;
+        const int k = lane / G, j = lane - k * G;
+        int lowest = y0, highest = y0, up = 0, dn = 0;
+        bool ok = false;
+        if (lane < K * G) {
+            const int y = y0 + k, x = x0 + j;
+            ok = x < W && y < H;
+            if (ok) {
+                const uint32_t a = sup[(size_t)y * W + x];
+                const int u = (int)(a & 31u), d = (int)((a >> 5) & 31u);
+                up = u < y ? u : y;
+                dn = d < H - 1 - y ? d : H - 1 - y;
+                lowest = y - up;
+                highest = dn > 0 ? y + dn : y0;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            lowest = min(lowest, __shfl_xor(lowest, d));
+            highest = max(highest, __shfl_xor(highest, d));
+        }
+        const int nd = y0 + K - 1 - lowest + 1;
+        if (lane < K * G) P.sched[k][j] = sched_of(ok, K, k, up, dn, nd);
+        if (lane == 0) {
+            P.y0 = y0;
+            P.x0 = x0;
+            P.nd = nd;
+            P.na = highest - y0;
+            P.row0 = y0 - R > 0 ? y0 - R : 0;
+        }
+    }
+    __syncthreads();
+    const RowTmp T = {{&tmp[0 * MAXG][lane], 64}, {&tmp[1 * MAXG][lane], 64}, {&tmp[2 * MAXG][lane], 64},
+                      {&tmp[3 * MAXG][lane], 64}, {&tmp[4 * MAXG][lane], 64}};
+    const int nsteps = P.nd + P.na;
+    // one pass: a lane's ops go to an LDS staging column first (their position in the program is known only once every
+    // lane has counted its own), then a wave scan places them
+    __shared__ uint32_t stage[kStageOps][64];
+    StageEmitter c = {&stage[0][lane], 0};
+    if (lane < nsteps) emit_row(L, P, sup, W, lane, T, c);
+    int incl = c.n;                                                   // inclusive scan over the lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    const int total = __shfl(incl, 63);
+    const uint32_t refill = (uint32_t)L.refill | ((uint32_t)L.M0 << 16);
+    WriteEmitter w = {out, incl - c.n, stride, refill};
+    for (int i = 0; i < c.n; ++i) w.op(stage[i][lane]);
+    if (lane == 0) {
+        WriteEmitter e = {out, total, stride, refill};
+        e.op((uint32_t)L.end | ((uint32_t)L.M0 << 16));
+    }
 }
 
 struct Shape {
@@ -101,6 +181,11 @@ static int shape_of(int D, int H, int W, Shape *s, const char *who)
     s->band_groups = s->band_rows / L.K;
     s->ngroups = cdiv(W, L.G);
     s->stride = stride_dwords(L.K, L.G, L.W);
+    {   // ops of one sweep step: windows + arm runs (cbca_prog_build.h, stride_dwords)
+        const int groups = L.K >= 2 ? L.K / 2 : 1, pieces = (R + 1 + L.W - 1) / L.W;
+        MCCNN_REQUIRE(pieces * (2 * L.G + 2 * L.G * groups) <= kStageOps, MCCNN_E_UNSUPPORTED,
+                      "%s: this layout's sweep steps exceed the builder's staging area", who);
+    }
     MCCNN_REQUIRE(s->ngroups <= 65535 && s->nchunks * 2 <= 65535, MCCNN_E_UNSUPPORTED, "%s: %dx%dx%d exceeds the grid", who,
                   W, H, D);
     return 0;
@@ -132,11 +217,12 @@ extern "C" int mccnn_cbca_prog_build_pair(const mccnn_support_t *support_left, c
     if (rc) return rc;
     rc = check_support_record(support_right, H, W, L, "mccnn_cbca_prog_build_pair", true);
     if (rc) return rc;
-    const dim3 grid(cdiv(s.ngroups, 64), 8 * s.band_groups, 2);
+    MCCNN_REQUIRE(8 * s.band_groups <= 65535, MCCNN_E_UNSUPPORTED, "mccnn_cbca_prog_build_pair: %d rows exceed the grid", H);
+    const dim3 grid(s.ngroups, 8 * s.band_groups, 2);
     hipLaunchKernelGGL(prog::cbca_prog_build_kernel, grid, dim3(64), 0, (hipStream_t)stream, prog::kLayouts[s.vpl - 2],
                        reinterpret_cast<const uint32_t *>(support_left), reinterpret_cast<const uint32_t *>(support_right),
                        reinterpret_cast<uint32_t *>(prog_left), reinterpret_cast<uint32_t *>(prog_right), H, W, s.ngroups,
-                       8 * s.band_groups, s.stride);
+                       s.stride);
     return check_launch("mccnn_cbca_prog_build_pair");
 }
 

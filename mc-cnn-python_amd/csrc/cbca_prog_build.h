@@ -57,29 +57,47 @@ MCCNN_PROG_HD int stride_dwords(int K, int G, int W)
     return (n + 63) / 64 * 64;
 }
 
-struct Emitter {
+// Raw op i of a program sits at dword i + i / 63: every 64-op chunk ends with a REFILL (the kernel keeps 64 ops per
+// lane-register and fetches the next chunk when it meets that op).
+struct CountEmitter {
+    int n;
+    MCCNN_PROG_HD void op(uint32_t) { ++n; }
+};
+struct WriteEmitter {
     uint32_t *out;
-    int n, cap;
+    int i, cap;
     uint32_t refill;
-    MCCNN_PROG_HD void put(uint32_t v)
-    {
-        if (n < cap) out[n] = v;
-        ++n;
-    }
     MCCNN_PROG_HD void op(uint32_t v)
     {
-        if ((n & 63) == 63) put(refill);
-        put(v);
+        const int f = i + i / 63;
+        if (f < cap) {
+            if (i > 0 && i % 63 == 0) out[f - 1] = refill;
+            out[f] = v;
+        }
+        ++i;
     }
 };
+MCCNN_PROG_HD int dwords_of(int raw_ops) { return raw_ops == 0 ? 0 : (raw_ops - 1) + (raw_ops - 1) / 63 + 1; }
+
+// The anchors of a patch: vertical arms clamped to the image, and the two sweeps they span.
+struct Patch {
+    int y0, x0, row0, nd, na;
+    // bit t: anchor (k, j) takes part in sweep step t.  Descending step s visits row y0 + K - 1 - s: anchor k is in for
+    // s in [K-1-k, K-1-k+up]; ascending step a (= step nd + a) visits row y0 + 1 + a: for a in [k, k+dn-1].
+    uint64_t sched[MAXK][MAXG];
+};
+MCCNN_PROG_HD uint64_t sched_of(bool ok, int K, int k, int up, int dn, int nd)
+{
+    if (!ok) return 0;
+    const uint64_t d = ((2ull << up) - 1ull) << (K - 1 - k);
+    const uint64_t a = (((1ull << dn) - 1ull) << k) << nd;
+    return d | a;
+}
 
 // sup0: plane 0 of the support buffer ([H][W] words: bits 0-4 up, 5-9 down, 10-14 left, 15-19 right).
-// Returns the number of dwords the program has (> cap: it did not fit, which the stride bound excludes).
-MCCNN_PROG_HD int build_patch(const Layout &L, const uint32_t *sup0, int H, int W, int y0, int x0, uint32_t *out, int cap)
+MCCNN_PROG_HD void patch_setup(const Layout &L, const uint32_t *sup0, int H, int W, int y0, int x0, Patch &P)
 {
-    const int K = L.K, G = L.G, WW = L.W;
-    const uint32_t M0 = (uint32_t)L.M0;
-    Emitter e = {out, 0, cap, (uint32_t)L.refill | (M0 << 16)};
+    const int K = L.K, G = L.G;
     int up[MAXK][MAXG], dn[MAXK][MAXG];
     bool ok[MAXK][MAXG];
     int lowest = y0, highest = y0;
@@ -99,28 +117,55 @@ MCCNN_PROG_HD int build_patch(const Layout &L, const uint32_t *sup0, int H, int 
             if (reach > highest) highest = reach;
         }
     }
-    const int nd = y0 + K - 1 - lowest + 1, na = highest - y0;
-    const int row0 = y0 - R > 0 ? y0 - R : 0;
-    for (int t = 0; t < nd + na; ++t) {
+    P.y0 = y0;
+    P.x0 = x0;
+    P.nd = y0 + K - 1 - lowest + 1;
+    P.na = highest - y0;
+    P.row0 = y0 - R > 0 ? y0 - R : 0;
+    for (int k = 0; k < K; ++k)
+        for (int j = 0; j < G; ++j) P.sched[k][j] = sched_of(ok[k][j], K, k, up[k][j], dn[k][j], P.nd);
+}
+
+// Per-row work arrays with run-time indices: plain stack arrays on the host, strided LDS on the device (private
+// "scratch" arrays cost a ~300-clock memory round trip per access there).
+struct Arr {
+    int *p;
+    int s;
+    MCCNN_PROG_HD int &operator[](int i) const { return p[i * s]; }
+};
+struct RowTmp {
+    Arr aset, cols, l, r, acols;
+};
+
+// The ops of sweep step t (one region row): its windows and arm runs, in execution order.
+template <class E>
+MCCNN_PROG_HD void emit_row(const Layout &L, const Patch &P, const uint32_t *sup0, int W, int t, const RowTmp &T, E &e)
+{
+    // every scalar of the layout and of the patch into registers first: on the device both live in LDS, next to the work
+    // arrays this function writes, so the compiler would otherwise reload them after every store
+    const int K = L.K, G = L.G, WW = L.W, MAXD = L.MAXD, MAXA = L.MAXA, BLK = L.BLK, RS = L.RS;
+    const uint32_t M0 = (uint32_t)L.M0;
+    const int y0 = P.y0, x0 = P.x0, nd = P.nd, row0 = P.row0;
+    {
         const int yq = t < nd ? y0 + K - 1 - t : y0 + 1 + (t - nd);
         // anchors taking part in this step
-        int aset[MAXG], cols[MAXG], ncols = 0;
+        const Arr aset = T.aset, cols = T.cols;
+        int ncols = 0;
         for (int j = 0; j < G; ++j) {
-            aset[j] = 0;
-            for (int k = 0; k < K; ++k) {
-                if (!ok[k][j]) continue;
-                const bool on = t < nd ? (K - 1 - k <= t && t <= K - 1 - k + up[k][j])
-                                       : (k <= t - nd && t - nd <= k + dn[k][j] - 1);
-                if (on) aset[j] |= 1 << k;
-            }
-            if (aset[j]) cols[ncols++] = j;
+            int m = 0;
+            for (int k = 0; k < K; ++k) m |= (int)((P.sched[k][j] >> t) & 1ull) << k;
+            aset[j] = m;
+            if (m) cols[ncols++] = j;
         }
-        if (ncols == 0) continue;
-        int l[MAXG], r[MAXG];
+        if (ncols == 0) return;
+        const Arr l = T.l, r = T.r;
+        // the row's G support words: unconditional, independent loads (words right of the image are never used and lie
+        // inside the support buffer, whose derived planes follow plane 0)
+        for (int j = 0; j < G; ++j) l[j] = (int)sup0[(size_t)yq * W + x0 + j];
         int lo = 1 << 30, hi = -1, maxl = 0, maxr = 0;
         for (int i = 0; i < ncols; ++i) {
             const int j = cols[i];
-            const uint32_t a = sup0[(size_t)yq * W + x0 + j];
+            const uint32_t a = (uint32_t)l[j];
             l[j] = (int)((a >> 10) & 31u);
             r[j] = (int)((a >> 15) & 31u);
             if (l[j] > R) l[j] = R;
@@ -145,20 +190,20 @@ MCCNN_PROG_HD int build_patch(const Layout &L, const uint32_t *sup0, int H, int 
                     const int m = ((1 << s) - 1) << st;
                     if ((rest & m) != m) continue;
                     rest &= ~m;
-                    const int maxn = dir ? L.MAXA : L.MAXD;
+                    const int maxn = dir ? MAXA : MAXD;
                     const int idx = dir ? sf + n - 1 : sf - n + 1;
-                    e.op((uint32_t)(L.add[j][m][dir] + (maxn - n) * L.BLK * s) | ((M0 | (uint32_t)(L.RS * idx)) << 16));
+                    e.op((uint32_t)(L.add[j][m][dir] + (maxn - n) * BLK * s) | ((M0 | (uint32_t)(RS * idx)) << 16));
                 }
         };
-        if (hi - lo + 1 <= WW && maxl + 1 <= L.MAXD && maxr <= L.MAXA) {
+        if (hi - lo + 1 <= WW && maxl + 1 <= MAXD && maxr <= MAXA) {
             load(lo, hi);
             for (int i = 0; i < ncols; ++i) run(cols[i], lo, cols[i] + R, l[cols[i]] + 1, 0);
             for (int i = 0; i < ncols; ++i)
                 if (r[cols[i]]) run(cols[i], lo, cols[i] + R + 1, r[cols[i]], 1);
-            continue;
+            return;
         }
         // wide row: windows over groups of neighbouring columns, descending arms first
-        const int capd = WW < L.MAXD ? WW : L.MAXD, capa = WW < L.MAXA ? WW : L.MAXA;
+        const int capd = WW < MAXD ? WW : MAXD, capa = WW < MAXA ? WW : MAXA;
         for (int i = 0; i < ncols;) {
             const int j = cols[i];
             int glo = j + R - l[j], ghi = j + R;
@@ -179,7 +224,7 @@ MCCNN_PROG_HD int build_patch(const Layout &L, const uint32_t *sup0, int H, int 
                 const int j2 = cols[i + cnt];
                 const int nlo = glo < j2 + R - l[j2] ? glo : j2 + R - l[j2];
                 const int nhi = ghi > j2 + R ? ghi : j2 + R;
-                if (nhi - nlo + 1 > WW || l[j2] + 1 > L.MAXD) break;
+                if (nhi - nlo + 1 > WW || l[j2] + 1 > MAXD) break;
                 glo = nlo;
                 ghi = nhi;
                 ++cnt;
@@ -188,7 +233,8 @@ MCCNN_PROG_HD int build_patch(const Layout &L, const uint32_t *sup0, int H, int 
             for (int q = 0; q < cnt; ++q) run(cols[i + q], glo, cols[i + q] + R, l[cols[i + q]] + 1, 0);
             i += cnt;
         }
-        int acols[MAXG], nac = 0;
+        const Arr acols = T.acols;
+        int nac = 0;
         for (int i = 0; i < ncols; ++i)
             if (r[cols[i]]) acols[nac++] = cols[i];
         for (int i = 0; i < nac;) {
@@ -211,7 +257,7 @@ MCCNN_PROG_HD int build_patch(const Layout &L, const uint32_t *sup0, int H, int 
                 const int j2 = acols[i + cnt];
                 const int nlo = glo < j2 + R + 1 ? glo : j2 + R + 1;
                 const int nhi = ghi > j2 + R + r[j2] ? ghi : j2 + R + r[j2];
-                if (nhi - nlo + 1 > WW || r[j2] > L.MAXA) break;
+                if (nhi - nlo + 1 > WW || r[j2] > MAXA) break;
                 glo = nlo;
                 ghi = nhi;
                 ++cnt;
@@ -221,9 +267,22 @@ MCCNN_PROG_HD int build_patch(const Layout &L, const uint32_t *sup0, int H, int 
             i += cnt;
         }
     }
-    e.op((uint32_t)L.end | (M0 << 16));
-    return e.n;
 }
+
+// The whole program of a patch, sequentially (host tests; the device kernel deals the rows to lanes, cbca_prog.hip).
+// Returns the number of dwords the program has (> cap: it did not fit, which the stride bound excludes).
+MCCNN_PROG_HD int build_patch(const Layout &L, const uint32_t *sup0, int H, int W, int y0, int x0, uint32_t *out, int cap)
+{
+    Patch P;
+    patch_setup(L, sup0, H, W, y0, x0, P);
+    WriteEmitter e = {out, 0, cap, (uint32_t)L.refill | ((uint32_t)L.M0 << 16)};
+    int buf[5][MAXG];
+    const RowTmp T = {{buf[0], 1}, {buf[1], 1}, {buf[2], 1}, {buf[3], 1}, {buf[4], 1}};
+    for (int t = 0; t < P.nd + P.na; ++t) emit_row(L, P, sup0, W, t, T, e);
+    e.op((uint32_t)L.end | ((uint32_t)L.M0 << 16));
+    return dwords_of(e.i);
+}
+
 
 }  // namespace prog
 }  // namespace mccnn

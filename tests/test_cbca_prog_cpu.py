@@ -107,12 +107,13 @@ def test_cxx_builder_equals_the_python_statement(tmp_path, vpl, k, w):
                                (31, 64, 5, True)):
         img, _ = make_case(H, W, 4, seed, flat)
         sup0 = np.ascontiguousarray(support_words(img))
+        padded = np.concatenate([sup0.reshape(-1), np.zeros(16, np.uint32)])   # the builder reads whole groups of G words
         assert lib.prog_band_rows(H) == ref.band_rows_of(H, k)
         for y0 in range(0, H, k):
             for x0 in range(0, W, L["G"]):
                 want = ref.build_program(sup0, H, W, y0, x0, L)
                 got = np.zeros(cap, np.uint32)
-                n = lib.prog_build_patch(sup0.ctypes.data_as(u32p), H, W, y0, x0, got.ctypes.data_as(u32p), cap)
+                n = lib.prog_build_patch(padded.ctypes.data_as(u32p), H, W, y0, x0, got.ctypes.data_as(u32p), cap)
                 assert n == len(want) <= cap, (H, W, y0, x0, n, len(want))
                 assert np.array_equal(got[:n], want), (H, W, y0, x0)
 

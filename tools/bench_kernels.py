@@ -91,7 +91,7 @@ def main():
                       "mccnn_sgm_first_pass")
         add("sgm_first_pass", first_pass, 4 * vol_bytes)
     # the pixel-major kernels of the bit-exact variant (two-volume launches like the pair runs them)
-    if not only or only & {"cbca_iter_hwd", "cbca_iter_hwd_pair", "wta_hwd"}:
+    if not only or only & {"cbca_iter_hwd", "cbca_iter_hwd_pair", "wta_hwd", "cbca_iter_prog_pair", "cbca_prog_build"}:
         hb, hb2 = torch.empty_like(hwd), torch.empty_like(hwd2)
         add("cbca_iter_hwd", lambda: sd.cbca_hwd(hwd, hb, sup, D, 1, 14), 2 * vol_bytes)
         add("cbca_iter_hwd_pair", lambda: sd.cbca_hwd_pair(hwd, hb, sup, hwd2, hb2, sup2, D, 1, 14), 4 * vol_bytes)
