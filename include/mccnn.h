@@ -174,7 +174,10 @@ int mccnn_cbca_iter_hwd_pair_wta(const float *in_left, float *out_left, const mc
  * depend on the image, on D (disparities per lane) and on nothing else: one build serves all 18 iterations of a pair.
  *   mccnn_cbca_prog_bytes: size of ONE image's program buffer; 0 when the shape is outside what the programs encode
  *     (W > 2180 columns, or volumes beyond a buffer descriptor's reach) - callers then stay with mccnn_cbca_iter_hwd_pair.
- *   support_*: the whole buffers mccnn_cross_arms wrote (plane 0 is read).  L <= 14; outputs must not alias inputs. */
+ *   support_*: the whole buffers mccnn_cross_arms wrote (plane 0 is read).  L <= 14; outputs must not alias inputs.
+ *   mccnn_cbca_iter_prog_pair refuses (MCCNN_E_INVALID) program buffers mccnn_cbca_prog_build_pair has not written, built
+ *   for another shape, or built from support arms that mccnn_cross_arms has overwritten since: the kernel follows its
+ *   programs blindly. */
 size_t mccnn_cbca_prog_bytes(int D, int H, int W);
 int mccnn_cbca_prog_build_pair(const mccnn_support_t *support_left, const mccnn_support_t *support_right, int D, int H,
                                int W, int L, void *prog_left, void *prog_right, mccnn_stream_t stream);

@@ -58,6 +58,8 @@ class Ins:
         a = ", ".join(_fmt(x) for x in self.args)
         m = ""
         for k, v in self.mods.items():
+            if k == "sim_skip":
+                continue
             if v is True:
                 m += " " + k
             elif v is not None and v is not False:
@@ -391,27 +393,49 @@ class Gen:
                 e("s_load_dword", sreg(S["cnt"] + k * G + j), sreg(S["t4"], 2), 4 * j)
         e("s_waitcnt", "lgkmcnt(0)")
         T = P.PHYS_WIN                                                  # the window is dead: temporaries
+        assert P.W * P.RS >= 1 + 5 * VPL, "the division's temporaries live in the window registers"
+        # pf:161 sum / n, correctly rounded like NumPy's float32 division: the compiler's own sequence (v_div_scale x 2,
+        # v_rcp, four fma, v_div_fmas, v_div_fixup), the VPL components of an anchor interleaved instruction by
+        # instruction so that no instruction waits for the one in front of it (each component's scale flags in an SGPR
+        # pair of its own, moved to VCC in front of its v_div_fmas).  (A reciprocal-based division - RN(1/n) once per
+        # anchor, then mul + 2 fma + fixup per component - is exact for normal quotients but rounds exact ties among
+        # subnormal quotients the wrong way, which the special-value test caught; not adopted.)
+        den = T
+        tmp = lambda c, i: T + 1 + 5 * c + i                           # a, r, t, b, q of component c
+        pairs = [S["t0"], S["t2"], S["t4"], S["dump"]]                  # SGPR pairs for the components' scale flags
         for k in range(K if not (P.debug & 1) else 0):               # debug 1: raw sums instead of quotients
             for j in range(G):
                 e("s_lshr_b32", s("t0"), sreg(S["cnt"] + k * G + j), 20)
-                e("v_cvt_f32_u32", vreg(T), s("t0"))
-                for c in range(VPL):
-                    num = P.acc(k, j, c)
-                    a, r, t, b, q = T + 1, T + 2, T + 3, T + 4, T + 5
-                    e("pseudo_div", vreg(num), vreg(T), 11)            # simulator: num /= den, skip the next 11
-                    e("v_div_scale_f32", vreg(a), sreg(S["t4"], 2), vreg(T), vreg(T), vreg(num))
-                    e("v_rcp_f32", vreg(r), vreg(a))
-                    # gfx940+ trans forwarding hazard: a VALU op may not read v_rcp's result in the next issue slot -
-                    # the independent second v_div_scale sits in between (and is >= 4 slots ahead of v_div_fmas' VCC read)
-                    e("v_div_scale_f32", vreg(b), "vcc", vreg(num), vreg(T), vreg(num))
-                    e("v_fma_f32", vreg(t), "-" + vreg(a), vreg(r), 1.0)
-                    e("v_fmac_f32", vreg(r), vreg(t), vreg(r))
-                    e("v_mul_f32", vreg(q), vreg(b), vreg(r))
-                    e("v_fma_f32", vreg(t), "-" + vreg(a), vreg(q), vreg(b))
-                    e("v_fmac_f32", vreg(q), vreg(t), vreg(r))
-                    e("v_fma_f32", vreg(a), "-" + vreg(a), vreg(q), vreg(b))
-                    e("v_div_fmas_f32", vreg(a), vreg(a), vreg(r), vreg(q))
-                    e("v_div_fixup_f32", vreg(num), vreg(a), vreg(T), vreg(num))
+                e("v_cvt_f32_u32", vreg(den), s("t0"))
+                C = range(VPL)
+                num = lambda c: P.acc(k, j, c)
+                for c in C:
+                    e("pseudo_div", vreg(num(c)), vreg(den), 0)       # simulator: the quotient; the real code follows
+                A, Rr, Tt, B, Q = 0, 1, 2, 3, 4
+                for c in C:
+                    e("v_div_scale_f32", vreg(tmp(c, A)), sreg(S["pfa"], 2), vreg(den), vreg(den), vreg(num(c)), sim_skip=True)
+                for c in C:
+                    e("v_rcp_f32", vreg(tmp(c, Rr)), vreg(tmp(c, A)), sim_skip=True)
+                for c in C:   # (also keeps every v_rcp result a slot away from its first reader: gfx940+ trans hazard)
+                    e("v_div_scale_f32", vreg(tmp(c, B)), sreg(pairs[c], 2), vreg(num(c)), vreg(den), vreg(num(c)), sim_skip=True)
+                for c in C:
+                    e("v_fma_f32", vreg(tmp(c, Tt)), "-" + vreg(tmp(c, A)), vreg(tmp(c, Rr)), 1.0, sim_skip=True)
+                for c in C:
+                    e("v_fmac_f32", vreg(tmp(c, Rr)), vreg(tmp(c, Tt)), vreg(tmp(c, Rr)), sim_skip=True)
+                for c in C:
+                    e("v_mul_f32", vreg(tmp(c, Q)), vreg(tmp(c, B)), vreg(tmp(c, Rr)), sim_skip=True)
+                for c in C:
+                    e("v_fma_f32", vreg(tmp(c, Tt)), "-" + vreg(tmp(c, A)), vreg(tmp(c, Q)), vreg(tmp(c, B)), sim_skip=True)
+                for c in C:
+                    e("v_fmac_f32", vreg(tmp(c, Q)), vreg(tmp(c, Tt)), vreg(tmp(c, Rr)), sim_skip=True)
+                for c in C:
+                    e("v_fma_f32", vreg(tmp(c, A)), "-" + vreg(tmp(c, A)), vreg(tmp(c, Q)), vreg(tmp(c, B)), sim_skip=True)
+                for c in C:
+                    e("s_mov_b64", "vcc", sreg(pairs[c], 2), sim_skip=True)
+                    e("s_nop", 1, sim_skip=True)
+                    e("v_div_fmas_f32", vreg(tmp(c, A)), vreg(tmp(c, A)), vreg(tmp(c, Rr)), vreg(tmp(c, Q)), sim_skip=True)
+                for c in C:
+                    e("v_div_fixup_f32", vreg(num(c)), vreg(tmp(c, A)), vreg(den), vreg(num(c)), sim_skip=True)
         # stores: per anchor row a descriptor that ends with the row / the image (columns past the edge are dropped)
         e("s_sub_u32", s("t5"), s("W"), s("x0"))
         e("s_min_i32", s("t5"), s("t5"), G)
@@ -432,7 +456,9 @@ class Gen:
             e("s_and_b32", sreg(S["rs_out"] + 1), sreg(S["rs_out"] + 1), 0xffff)
             e("s_mov_b32", s("so"), 0)
             for j in range(G):
-                self.vstore(P.acc(k, j), P.v_voff, S["rs_out"], s("so"), nt=True)
+                pol = {0: dict(nt=True), 4: {}, 8: dict(sc1=True), 12: dict(sc0=True, sc1=True), 16: dict(sc1=True, nt=True),
+                       20: dict(sc0=True, sc1=True, nt=True)}[P.debug & 28]      # debug 4..20: other cache policies
+                self.vstore(P.acc(k, j), P.v_voff, S["rs_out"], s("so"), **pol)
                 e("s_nop", 0, comment="gfx950 store-data hazard (common.h)")
                 if j + 1 < G:
                     e("s_add_u32", s("so"), s("so"), s("pix"))

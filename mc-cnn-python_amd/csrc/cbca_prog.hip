@@ -11,6 +11,7 @@
 // The assembled code objects are embedded in this library (build/asm/cbca_prog_v{2,3,4}.inc, Makefile) and loaded
 // through the HIP module API on first use, once per device.
 #include <mutex>
+#include <unordered_map>
 
 #include "cbca_prog_build.h"
 #include "cbca_prog_layout_v2.h"
@@ -161,6 +162,32 @@ struct Shape {
     int vpl, Dp, nchunks, band_rows, band_groups, ngroups, stride;
 };
 
+// What mccnn_cbca_prog_build_pair last wrote where: the interpreter kernel follows whatever its program buffer holds,
+// so a buffer that was never built (or built for another shape, or from support arms that have been overwritten since)
+// must never reach it - it would not fail, it would run away.
+struct Built {
+    int D, H, W;
+    const void *support;
+    unsigned long long gen;
+};
+static std::unordered_map<const void *, Built> g_built;
+static std::mutex g_built_mu;
+
+static int check_built(const void *prog, const mccnn_support_t *support, int D, int H, int W)
+{
+    std::lock_guard<std::mutex> lock(g_built_mu);
+    const auto it = g_built.find(prog);
+    MCCNN_REQUIRE(it != g_built.end(), MCCNN_E_INVALID,
+                  "mccnn_cbca_iter_prog_pair: this program buffer has not been written by mccnn_cbca_prog_build_pair");
+    const Built &b = it->second;
+    MCCNN_REQUIRE(b.D == D && b.H == H && b.W == W, MCCNN_E_INVALID,
+                  "mccnn_cbca_iter_prog_pair: programs were built for %dx%dx%d, called with %dx%dx%d", b.W, b.H, b.D, W, H, D);
+    MCCNN_REQUIRE(b.support == support && b.gen == support_generation(support), MCCNN_E_INVALID,
+                  "mccnn_cbca_iter_prog_pair: programs are stale: mccnn_cross_arms has rewritten the support buffer (or "
+                  "another one is passed) since mccnn_cbca_prog_build_pair");
+    return 0;
+}
+
 // 0 when the program-driven kernels serve this shape (then *s is filled), else the reason as an error code
 static int shape_of(int D, int H, int W, Shape *s, const char *who)
 {
@@ -223,7 +250,13 @@ extern "C" int mccnn_cbca_prog_build_pair(const mccnn_support_t *support_left, c
                        reinterpret_cast<const uint32_t *>(support_left), reinterpret_cast<const uint32_t *>(support_right),
                        reinterpret_cast<uint32_t *>(prog_left), reinterpret_cast<uint32_t *>(prog_right), H, W, s.ngroups,
                        s.stride);
-    return check_launch("mccnn_cbca_prog_build_pair");
+    rc = check_launch("mccnn_cbca_prog_build_pair");
+    if (rc == 0) {
+        std::lock_guard<std::mutex> lock(prog::g_built_mu);
+        prog::g_built[prog_left] = prog::Built{D, H, W, support_left, support_generation(support_left)};
+        prog::g_built[prog_right] = prog::Built{D, H, W, support_right, support_generation(support_right)};
+    }
+    return rc;
 }
 
 extern "C" int mccnn_cbca_iter_prog_pair(const float *in_left, float *out_left, const mccnn_support_t *support_left,
@@ -244,6 +277,10 @@ extern "C" int mccnn_cbca_iter_prog_pair(const float *in_left, float *out_left, 
     rc = check_support_record(support_left, H, W, L, "mccnn_cbca_iter_prog_pair", true);
     if (rc) return rc;
     rc = check_support_record(support_right, H, W, L, "mccnn_cbca_iter_prog_pair", true);
+    if (rc) return rc;
+    rc = prog::check_built(prog_left, support_left, D, H, W);
+    if (rc) return rc;
+    rc = prog::check_built(prog_right, support_right, D, H, W);
     if (rc) return rc;
     hipFunction_t fn;
     rc = prog::kernel_for(s.vpl, &fn);

@@ -895,10 +895,18 @@ static int launch_cbca_stream(const StreamJobs &jobs, int D, int H, int W, hipSt
 // kernel and its halo).  Pointers it has never seen (e.g. a device-side copy) pass: the kernels are memory-safe for
 // any arms (clamped above / baked within range), only the sums would be those of the clamped region.
 namespace {
-struct SupportInfo { int H, W, L; };
+struct SupportInfo { int H, W, L; unsigned long long gen; };
 std::mutex g_support_mu;
 std::unordered_map<const void *, SupportInfo> g_support;
+unsigned long long g_support_gen = 0;     // counts mccnn_cross_arms calls: what was derived from a buffer can tell if it is stale
 }  // namespace
+
+unsigned long long mccnn::support_generation(const mccnn_support_t *support)
+{
+    std::lock_guard<std::mutex> lock(g_support_mu);
+    const auto it = g_support.find(support);
+    return it == g_support.end() ? 0ull : it->second.gen;
+}
 
 int mccnn::check_support_record(const mccnn_support_t *support, int H, int W, int L, const char *who, bool must_be_known)
 {
@@ -933,8 +941,8 @@ static int launch_cross_arms(const float *img0, const float *img1, mccnn_support
     if (rc == 0) {
         std::lock_guard<std::mutex> lock(g_support_mu);
         if (g_support.size() > 4096) g_support.clear();   // bounded: stale entries only cost a missed check
-        g_support[sup0] = SupportInfo{H, W, L};
-        g_support[sup1] = SupportInfo{H, W, L};
+        g_support[sup0] = SupportInfo{H, W, L, ++g_support_gen};
+        g_support[sup1] = SupportInfo{H, W, L, ++g_support_gen};
     }
     return rc;
 }

@@ -64,5 +64,7 @@ __host__ __device__ __forceinline__ size_t wmask_plane_bytes(int H, int W)
 // another image size or with longer arms than the caller states; unknown pointers pass unless must_be_known (the
 // pixel-major kernels read planes behind plane 0, which only a buffer written by mccnn_cross_arms has).
 int check_support_record(const mccnn_support_t *support, int H, int W, int L, const char *who, bool must_be_known = false);
+// Generation of the buffer's contents: every mccnn_cross_arms write gets a new one (0: never written).
+unsigned long long support_generation(const mccnn_support_t *support);
 
 }  // namespace mccnn

@@ -249,12 +249,27 @@ class Wave:
             if trace is not None:
                 trace.append((pc - 1, i))
             op, a = i.op, i.args
+            if i.mods.get("sim_skip"):          # real instructions of a sequence a pseudo op has already evaluated
+                self.stats["valu"] += 1
+                continue
             if op.startswith("s_") or op.startswith("pseudo"):
                 self.stats["salu"] += 1
             if op == "s_endpgm":
                 if self.pending and False:
                     raise SimError("loads in flight at s_endpgm")
                 return self.stats
+            elif op == "pseudo_rcp":
+                dst, den, skip = a
+                d = self.vrange(den)[0]
+                self._check_ready(d)
+                with np.errstate(all="ignore"):
+                    self.v[self.vrange(dst)[0]] = (np.float32(1.0) / f32(self.v[d])).astype(np.float32).view(np.uint32)
+                self.stats["valu"] += skip
+                k = 0
+                while k < skip:
+                    if self.ins[pc].op != "label":
+                        k += 1
+                    pc += 1
             elif op == "pseudo_div":
                 num, den, skip = a
                 n = self.vrange(num)[0]

@@ -97,6 +97,7 @@ def main():
         add("cbca_iter_hwd_pair", lambda: sd.cbca_hwd_pair(hwd, hb, sup, hwd2, hb2, sup2, D, 1, 14), 4 * vol_bytes)
         progs = sd.cbca_prog_buffers(D, H, W, hwd.device)
         if progs is not None:
+            sd.cbca_prog_build_pair(sup, sup2, D, 14, progs)
             add("cbca_prog_build", lambda: sd.cbca_prog_build_pair(sup, sup2, D, 14, progs), 0.0)
             add("cbca_iter_prog_pair", lambda: sd.cbca_prog_pair(hwd, hb, sup, hwd2, hb2, sup2, progs, D, 1, 14), 4 * vol_bytes)
         add("wta_hwd", lambda: sd.wta_hwd(hwd, D), vol_bytes)

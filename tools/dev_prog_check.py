@@ -208,6 +208,10 @@ def main():
         variant(1.0, 0)
         variant(1.0, 1.0)
         variant(0.0, 1.0)
+        for dbg, note in ((4, "plain stores"), (8, "sc1 stores"), (12, "sc0 sc1 stores"), (16, "sc1 nt stores"), (20, "sc0 sc1 nt stores")):
+            g2, path2 = build_hsaco(vpl, args.w, os.path.join(ROOT, "mc-cnn-python_amd", "build", "asm"), args.nb, dbg)
+            m2 = Module(path2, g2.P.name())
+            variant(0.0, 0.0, m2, note)
         for dbg, note in ((1, "no division"), (2, "no stores"), (3, "no division, no stores")):
             g2, path2 = build_hsaco(vpl, args.w, os.path.join(ROOT, "mc-cnn-python_amd", "build", "asm"), args.nb, dbg)
             m2 = Module(path2, g2.P.name())
