@@ -185,6 +185,13 @@ int mccnn_cbca_iter_prog_pair(const float *in_left, float *out_left, const mccnn
                               const void *prog_left, const float *in_right, float *out_right,
                               const mccnn_support_t *support_right, const void *prog_right, int D, int H, int W, int L,
                               mccnn_stream_t stream);
+/* The last iteration fused with a7 (pf:239-272), like mccnn_cbca_iter_hwd_pair_wta: also writes the first strict minimum
+ * over d of both results to disparity_left / disparity_right ([H][W] float32, -1 where nothing wins); store_right = 0
+ * leaves out_right unwritten (it may then be NULL).  One chunk of disparities per wave: D <= 256. */
+int mccnn_cbca_iter_prog_pair_wta(const float *in_left, float *out_left, const mccnn_support_t *support_left,
+                                  const void *prog_left, const float *in_right, float *out_right,
+                                  const mccnn_support_t *support_right, const void *prog_right, int D, int H, int W, int L,
+                                  float *disparity_left, float *disparity_right, int store_right, mccnn_stream_t stream);
 
 /* ---- layout changes between DHW and HWD ------------------------------------------------------------------- */
 int mccnn_hwd_pitch(int D); /* Dp: D rounded up to a multiple of 4 (16-byte rows) */

@@ -58,7 +58,7 @@ class Ins:
         a = ", ".join(_fmt(x) for x in self.args)
         m = ""
         for k, v in self.mods.items():
-            if k == "sim_skip":
+            if k in ("sim_skip", "dpp"):
                 continue
             if v is True:
                 m += " " + k
@@ -85,7 +85,7 @@ SOPP = {"s_waitcnt", "s_branch", "s_cbranch_scc0", "s_cbranch_scc1", "s_cbranch_
         "s_endpgm", "s_set_gpr_idx_off", "s_barrier", "s_cbranch_execz"}
 SOPK = {"s_movk_i32"}
 SMEM = {"s_load_dword", "s_load_dwordx2", "s_load_dwordx4", "s_load_dwordx8", "s_load_dwordx16"}
-VOP3 = {"v_pk_add_f32", "v_readlane_b32", "v_fma_f32", "v_div_scale_f32", "v_div_fmas_f32", "v_div_fixup_f32", "v_mul_lo_u32",
+VOP3 = {"v_cmp_lt_f32_e64", "v_cmp_eq_f32_e64", "v_pk_add_f32", "v_readlane_b32", "v_fma_f32", "v_div_scale_f32", "v_div_fmas_f32", "v_div_fixup_f32", "v_mul_lo_u32",
         "v_mad_u32_u24", "v_cndmask_b32_e64", "v_cmp_lt_f32_e64", "v_cmp_eq_f32_e64", "v_cmp_gt_u32_e64",
         "v_min3_f32", "v_lshl_add_u32"}
 MUBUF = {"buffer_load_dword", "buffer_load_dwordx2", "buffer_load_dwordx3", "buffer_load_dwordx4",
@@ -244,6 +244,8 @@ class Gen:
         self.label("entry")
         e("s_load_dwordx16", s("ka", 16), s("karg", 2), 0x0)
         e("s_load_dwordx8", s("Dp", 8), s("karg", 2), 0x40)
+        if P.wta:
+            e("s_load_dwordx8", s("disp", 8), s("karg", 2), 0x60)
         e("s_waitcnt", "lgkmcnt(0)")
         # y0 = (bx & 7) * band_rows + (bx >> 3) * K ; patch row group = (bx & 7) * band_groups + (bx >> 3)
         e("s_and_b32", s("t0"), s("bx"), 7)
@@ -266,6 +268,9 @@ class Gen:
         e("s_cselect_b64", s("outp", 2), sreg(S["ka"] + 6, 2), sreg(S["ka"] + 4, 2))
         e("s_cselect_b64", s("progp", 2), sreg(S["ka"] + 10, 2), sreg(S["ka"] + 8, 2))
         e("s_cselect_b64", s("supp", 2), sreg(S["ka"] + 14, 2), sreg(S["ka"] + 12, 2))
+        if P.wta:
+            e("s_cselect_b64", s("dispp", 2), sreg(S["disp"] + 2, 2), sreg(S["disp"] + 0, 2))
+            e("s_cselect_b32", s("store1"), s("store1"), 1, comment="job 0 is always stored, job 1 if store1")
         e("s_sub_u32", s("chunk"), s("bz"), s("t1"))
         # program of this patch: one dword per lane, two 64-op chunks in flight
         e("s_mul_hi_u32", s("t2"), s("t0"), s("prog_stride"))
@@ -447,6 +452,9 @@ class Gen:
             e("s_cselect_b32", sreg(S["rs_out"] + 2), s("t5"), 0)
             if P.debug & 2:                                             # debug 2 (timing only): nothing is stored
                 e("s_mov_b32", sreg(S["rs_out"] + 2), 0)
+            if P.wta:                                                   # a right volume nothing reads is not written
+                e("s_cmp_eq_u32", s("store1"), 0)
+                e("s_cselect_b32", sreg(S["rs_out"] + 2), 0, sreg(S["rs_out"] + 2))
             e("s_mul_i32", s("t0"), s("t0"), s("W"))
             e("s_add_u32", s("t0"), s("t0"), s("x0"))
             e("s_mul_hi_u32", s("t2"), s("t0"), s("pix"))
@@ -462,9 +470,87 @@ class Gen:
                 e("s_nop", 0, comment="gfx950 store-data hazard (common.h)")
                 if j + 1 < G:
                     e("s_add_u32", s("so"), s("so"), s("pix"))
+        if P.wta:
+            self.wta_tail()
         self.label("done")
         e("s_endpgm")
         return self
+
+    # a7 fused into the last iteration (pf:245-254): the first strict minimum over d of every result pixel - the two
+    # wave reductions of wta_hwd_kernel (cbca_hwd.hip) on the quotients the wave still holds: the minimum, then the
+    # lowest index among the lanes that hold it; NaN never wins, -1 when nothing does.  One chunk of disparities.
+    def wta_tail(self):
+        P, e = self.P, self.e
+        K, G, VPL = P.K, P.G, P.VPL
+        s = lambda n, c=1: sreg(S[n], c) if isinstance(n, str) else sreg(n, c)
+        T = P.PHYS_WIN
+        best, bd, d0v, tmp, lane0off = T, T + 1, T + 2, T + 3, T + 4
+        dpp = [("quad_perm:[1,0,3,2]", None), ("quad_perm:[2,3,0,1]", None), ("row_half_mirror", None),
+               ("row_mirror", None), ("row_bcast:15", "0xa"), ("row_bcast:31", "0xc")]
+        e("pseudo_wta", P.nacc, comment="simulator: evaluates the whole tail below")
+        k0 = len(self.ins)
+        sk = dict(sim_skip=True)
+        # d0 of this lane = lane * VPL; voffset of the map store: 0 in lane 0, out of range elsewhere
+        e("v_lshrrev_b32", vreg(d0v), 2, vreg(P.v_lane4), **sk)
+        e("v_mul_u32_u24", vreg(d0v), VPL, vreg(d0v), **sk)
+        e("v_mov_b32", vreg(lane0off), KDROP, **sk)
+        e("v_cmp_eq_u32", "vcc", 0, vreg(P.v_lane4), **sk)
+        e("v_cndmask_b32", vreg(lane0off), vreg(lane0off), vreg(P.v_lane4), "vcc", **sk)   # lane 0: lane4 = 0
+        # descriptor over the disparity map
+        e("s_mov_b32", sreg(S["rs_out"] + 0), s("dispp"), **sk)
+        e("s_and_b32", sreg(S["rs_out"] + 1), sreg(S["dispp"] + 1), 0xffff, **sk)
+        e("s_mul_i32", s("t5"), s("H"), s("W"), **sk)
+        e("s_lshl_b32", s("t5"), s("t5"), 2, **sk)
+        e("s_mov_b32", sreg(S["rs_out"] + 3), 0x00020000, **sk)
+        for k in range(K):
+            for j in range(G):
+                e("v_mov_b32", vreg(best), 0x7f800000, **sk)
+                e("v_mov_b32", vreg(bd), -1, **sk)
+                for c in range(VPL):
+                    # if (d0 + c < D && v < best) { best = v; bd = d0 + c; }
+                    e("v_add_u32", vreg(tmp), c, vreg(d0v), **sk)
+                    e("v_cmp_gt_u32", "vcc", s("D"), vreg(tmp), **sk)
+                    e("v_cmp_lt_f32_e64", sreg(S["t2"], 2), vreg(P.acc(k, j, c)), vreg(best), **sk)
+                    e("s_and_b64", "vcc", "vcc", sreg(S["t2"], 2), **sk)
+                    e("s_nop", 1, **sk)
+                    e("v_cndmask_b32", vreg(best), vreg(best), vreg(P.acc(k, j, c)), "vcc", **sk)
+                    e("v_cndmask_b32", vreg(bd), vreg(bd), vreg(tmp), "vcc", **sk)
+                # wave minimum of best into lane 63 (lanes without a DPP source keep their own value)
+                e("v_mov_b32", vreg(tmp), vreg(best), **sk)
+                for ctrl, rowmask in dpp:
+                    m = dict(row_mask=rowmask) if rowmask else {}
+                    e("s_nop", 1, **sk)
+                    e("v_min_f32_dpp", vreg(tmp), vreg(tmp), vreg(tmp), ctrl, dpp=True, **m, **sk)
+                e("s_nop", 1, **sk)
+                e("v_readlane_b32", s("t0"), vreg(tmp), 63, **sk)
+                # candidates: lanes holding the minimum offer their index, the others INT_MAX
+                e("v_cmp_eq_f32_e64", sreg(S["t2"], 2), s("t0"), vreg(best), **sk)
+                e("v_cmp_le_i32", "vcc", 0, vreg(bd), **sk)
+                e("s_and_b64", "vcc", "vcc", sreg(S["t2"], 2), **sk)
+                e("v_mov_b32", vreg(tmp), 0x7fffffff, **sk)
+                e("s_nop", 1, **sk)
+                e("v_cndmask_b32", vreg(tmp), vreg(tmp), vreg(bd), "vcc", **sk)
+                for ctrl, rowmask in dpp:
+                    m = dict(row_mask=rowmask) if rowmask else {}
+                    e("s_nop", 1, **sk)
+                    e("v_min_i32_dpp", vreg(tmp), vreg(tmp), vreg(tmp), ctrl, dpp=True, **m, **sk)
+                e("s_nop", 1, **sk)
+                e("v_readlane_b32", s("t0"), vreg(tmp), 63, **sk)
+                # disp[(y0 + k) * W + x0 + j] = idx == INT_MAX ? -1 : idx, by lane 0, for pixels inside the image
+                e("s_cmp_eq_u32", s("t0"), 0x7fffffff, **sk)
+                e("s_cselect_b32", s("t0"), -1, s("t0"), **sk)
+                e("v_cvt_f32_i32", vreg(tmp), s("t0"), **sk)
+                e("s_add_u32", s("t1"), s("y0"), k, **sk)
+                e("s_add_u32", s("t3"), s("x0"), j, **sk)
+                e("s_cmp_lt_i32", s("t1"), s("H"), **sk)
+                e("s_cselect_b32", s("t4"), s("t5"), 0, **sk)
+                e("s_cmp_lt_i32", s("t3"), s("W"), **sk)
+                e("s_cselect_b32", sreg(S["rs_out"] + 2), s("t4"), 0, **sk)
+                e("s_mul_i32", s("t1"), s("t1"), s("W"), **sk)
+                e("s_add_u32", s("t1"), s("t1"), s("t3"), **sk)
+                e("s_lshl_b32", s("t1"), s("t1"), 2, **sk)
+                e("buffer_store_dword", vreg(tmp), vreg(lane0off), sreg(S["rs_out"], 4), s("t1"), offen=True, **sk)
+        self.ins[k0 - 1].args.append(len(self.ins) - k0)
 
     def prefetch(self):
         """L2 warm-up through the SCALAR cache path.  The vector memory pipe of a CU keeps ~32 KiB of requests in

@@ -32,8 +32,19 @@ alignas(4096) static const unsigned char kCodeV3[] = {
 alignas(4096) static const unsigned char kCodeV4[] = {
 #include "cbca_prog_v4.inc"
 };
-static const unsigned char *const kCode[3] = {kCodeV2, kCodeV3, kCodeV4};
-static const char *const kName[3] = {"mccnn_cbca_prog_v2", "mccnn_cbca_prog_v3", "mccnn_cbca_prog_v4"};
+alignas(4096) static const unsigned char kCodeV2w[] = {
+#include "cbca_prog_v2w.inc"
+};
+alignas(4096) static const unsigned char kCodeV3w[] = {
+#include "cbca_prog_v3w.inc"
+};
+alignas(4096) static const unsigned char kCodeV4w[] = {
+#include "cbca_prog_v4w.inc"
+};
+// [with WTA][disparities per lane - 2]
+static const unsigned char *const kCode[2][3] = {{kCodeV2, kCodeV3, kCodeV4}, {kCodeV2w, kCodeV3w, kCodeV4w}};
+static const char *const kName[2][3] = {{"mccnn_cbca_prog_v2", "mccnn_cbca_prog_v3", "mccnn_cbca_prog_v4"},
+                                        {"mccnn_cbca_prog_v2_wta", "mccnn_cbca_prog_v3_wta", "mccnn_cbca_prog_v4_wta"}};
 
 // disparities per lane: 2 up to 128, 3 where that fills the lanes exactly (padded D a multiple of 3 up to 192), else 4
 // with 256-disparity chunks - the same rule as cbca_hwd.hip
@@ -43,22 +54,22 @@ struct Loaded {
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
 };
-static Loaded g_loaded[64][3];
+static Loaded g_loaded[64][2][3];
 static std::mutex g_mu;
 
-static int kernel_for(int vpl, hipFunction_t *fn)
+static int kernel_for(int vpl, bool wta, hipFunction_t *fn)
 {
     int dev = 0;
     MCCNN_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, MCCNN_E_UNSUPPORTED,
                   "mccnn_cbca_iter_prog_pair: no current device");
     std::lock_guard<std::mutex> lock(g_mu);
-    Loaded &l = g_loaded[dev][vpl - 2];
+    Loaded &l = g_loaded[dev][wta ? 1 : 0][vpl - 2];
     if (!l.fn) {
-        hipError_t e = hipModuleLoadData(&l.mod, kCode[vpl - 2]);
+        hipError_t e = hipModuleLoadData(&l.mod, kCode[wta ? 1 : 0][vpl - 2]);
         MCCNN_REQUIRE(e == hipSuccess, (int)e, "mccnn_cbca_iter_prog_pair: hipModuleLoadData: %s", hipGetErrorString(e));
-        e = hipModuleGetFunction(&l.fn, l.mod, kName[vpl - 2]);
-        MCCNN_REQUIRE(e == hipSuccess, (int)e, "mccnn_cbca_iter_prog_pair: hipModuleGetFunction(%s): %s", kName[vpl - 2],
-                      hipGetErrorString(e));
+        e = hipModuleGetFunction(&l.fn, l.mod, kName[wta ? 1 : 0][vpl - 2]);
+        MCCNN_REQUIRE(e == hipSuccess, (int)e, "mccnn_cbca_iter_prog_pair: hipModuleGetFunction(%s): %s",
+                      kName[wta ? 1 : 0][vpl - 2], hipGetErrorString(e));
     }
     *fn = l.fn;
     return 0;
@@ -259,44 +270,71 @@ extern "C" int mccnn_cbca_prog_build_pair(const mccnn_support_t *support_left, c
     return rc;
 }
 
-extern "C" int mccnn_cbca_iter_prog_pair(const float *in_left, float *out_left, const mccnn_support_t *support_left,
-                                         const void *prog_left, const float *in_right, float *out_right,
-                                         const mccnn_support_t *support_right, const void *prog_right, int D, int H, int W,
-                                         int L, mccnn_stream_t stream)
+static int prog_iter(const char *who, const float *in_left, float *out_left, const mccnn_support_t *support_left,
+                     const void *prog_left, const float *in_right, float *out_right, const mccnn_support_t *support_right,
+                     const void *prog_right, int D, int H, int W, int L, float *disp_left, float *disp_right,
+                     int store_right, bool wta, mccnn_stream_t stream)
 {
     using namespace mccnn;
-    MCCNN_REQUIRE(in_left && out_left && support_left && prog_left && in_right && out_right && support_right && prog_right,
-                  MCCNN_E_INVALID, "mccnn_cbca_iter_prog_pair: null pointer");
-    MCCNN_REQUIRE(in_left != out_left && in_right != out_right && out_left != out_right && in_left != out_right &&
-                      in_right != out_left,
-                  MCCNN_E_INVALID, "mccnn_cbca_iter_prog_pair: outputs must not alias an input or each other");
-    MCCNN_REQUIRE(L >= 1 && L <= 14, MCCNN_E_UNSUPPORTED, "mccnn_cbca_iter_prog_pair: L=%d outside [1,14]", L);
+    MCCNN_REQUIRE(in_left && out_left && support_left && prog_left && in_right && support_right && prog_right,
+                  MCCNN_E_INVALID, "%s: null pointer", who);
+    MCCNN_REQUIRE(out_right || (wta && !store_right), MCCNN_E_INVALID, "%s: out_right is null", who);
+    MCCNN_REQUIRE(!wta || (disp_left && disp_right), MCCNN_E_INVALID, "%s: null disparity map", who);
+    if (!out_right) out_right = out_left;     // never dereferenced: the kernel gets an empty descriptor for it
+    MCCNN_REQUIRE(in_left != out_left && in_right != out_right && (out_left != out_right || !store_right) &&
+                      in_left != out_right && in_right != out_left,
+                  MCCNN_E_INVALID, "%s: outputs must not alias an input or each other", who);
+    MCCNN_REQUIRE(L >= 1 && L <= 14, MCCNN_E_UNSUPPORTED, "%s: L=%d outside [1,14]", who, L);
     prog::Shape s;
-    int rc = prog::shape_of(D, H, W, &s, "mccnn_cbca_iter_prog_pair");
+    int rc = prog::shape_of(D, H, W, &s, who);
     if (rc) return rc;
-    rc = check_support_record(support_left, H, W, L, "mccnn_cbca_iter_prog_pair", true);
+    MCCNN_REQUIRE(!wta || s.nchunks == 1, MCCNN_E_UNSUPPORTED,
+                  "%s: D=%d spans more than one chunk of a wave (use mccnn_wta_hwd)", who, D);
+    rc = check_support_record(support_left, H, W, L, who, true);
     if (rc) return rc;
-    rc = check_support_record(support_right, H, W, L, "mccnn_cbca_iter_prog_pair", true);
+    rc = check_support_record(support_right, H, W, L, who, true);
     if (rc) return rc;
     rc = prog::check_built(prog_left, support_left, D, H, W);
     if (rc) return rc;
     rc = prog::check_built(prog_right, support_right, D, H, W);
     if (rc) return rc;
     hipFunction_t fn;
-    rc = prog::kernel_for(s.vpl, &fn);
+    rc = prog::kernel_for(s.vpl, wta, &fn);
     if (rc) return rc;
     struct {
         const void *in0, *in1;
         void *out0, *out1;
         const void *prog0, *prog1, *sup0, *sup1;
         int Dp, H, W, nchunks, band_rows, band_groups, prog_stride_bytes, ngroups;
+        void *disp0, *disp1;
+        int D, store1, pad0, pad1;
     } args = {in_left, in_right, out_left, out_right, prog_left, prog_right, support_left, support_right,
-              s.Dp, H, W, s.nchunks, s.band_rows, s.band_groups, s.stride * 4, s.ngroups};
-    static_assert(sizeof(args) == 0x60, "kernarg layout of csrc/asm/cbca_prog_gen.py");
-    size_t size = sizeof(args);
+              s.Dp, H, W, s.nchunks, s.band_rows, s.band_groups, s.stride * 4, s.ngroups,
+              disp_left, disp_right, D, store_right ? 1 : 0, 0, 0};
+    static_assert(sizeof(args) == 0x80, "kernarg layout of csrc/asm/cbca_prog_gen.py");
+    size_t size = wta ? 0x80 : 0x60;
     void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
     const hipError_t e = hipModuleLaunchKernel(fn, 8 * s.band_groups, s.ngroups, s.nchunks * 2, 64, 1, 1, 0,
                                                (hipStream_t)stream, nullptr, extra);
-    MCCNN_REQUIRE(e == hipSuccess, (int)e, "mccnn_cbca_iter_prog_pair: %s", hipGetErrorString(e));
+    MCCNN_REQUIRE(e == hipSuccess, (int)e, "%s: %s", who, hipGetErrorString(e));
     return 0;
+}
+
+extern "C" int mccnn_cbca_iter_prog_pair(const float *in_left, float *out_left, const mccnn_support_t *support_left,
+                                         const void *prog_left, const float *in_right, float *out_right,
+                                         const mccnn_support_t *support_right, const void *prog_right, int D, int H, int W,
+                                         int L, mccnn_stream_t stream)
+{
+    return prog_iter("mccnn_cbca_iter_prog_pair", in_left, out_left, support_left, prog_left, in_right, out_right,
+                     support_right, prog_right, D, H, W, L, nullptr, nullptr, 1, false, stream);
+}
+
+extern "C" int mccnn_cbca_iter_prog_pair_wta(const float *in_left, float *out_left, const mccnn_support_t *support_left,
+                                             const void *prog_left, const float *in_right, float *out_right,
+                                             const mccnn_support_t *support_right, const void *prog_right, int D, int H,
+                                             int W, int L, float *disparity_left, float *disparity_right, int store_right,
+                                             mccnn_stream_t stream)
+{
+    return prog_iter("mccnn_cbca_iter_prog_pair_wta", in_left, out_left, support_left, prog_left, in_right, out_right,
+                     support_right, prog_right, D, H, W, L, disparity_left, disparity_right, store_right, true, stream);
 }

@@ -345,9 +345,11 @@ def cbca_prog_build_pair(support_l, support_r, D, distance_threshold, progs):
     return progs
 
 
-def cbca_prog_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, progs, D, iterations, distance_threshold, timer=None):
+def cbca_prog_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, progs, D, iterations, distance_threshold, timer=None,
+                   wta_out=None, store_right=True):
     """cbca_hwd_pair's result (bit for bit) through the program-driven assembly kernel (mccnn_cbca_iter_prog_pair);
-    `progs` from cbca_prog_build_pair on the same support buffers and D.  Same ping-pong contract."""
+    `progs` from cbca_prog_build_pair on the same support buffers and D.  Same ping-pong contract; wta_out /
+    store_right as in cbca_hwd_pair (mccnn_cbca_iter_prog_pair_wta for the last iteration)."""
     H, W, Dp = vol_l.shape
     assert Dp == hwd_pitch(D)
     for t in (tmp_l, vol_r, tmp_r):
@@ -358,11 +360,25 @@ def cbca_prog_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, progs, D, i
     lib = hip.load()
     (sl, dl), (sr, dr) = (vol_l, tmp_l), (vol_r, tmp_r)
     timer = timer or _NO_TIMER
-    for _ in range(int(iterations)):
+    n = int(iterations)
+    if wta_out is not None and (n < 1 or D > cbca_hwd_wta_max_d()):
+        raise ValueError("cbca_prog_pair: the fused WTA needs at least one iteration and D <= %d" % cbca_hwd_wta_max_d())
+    for it in range(n):
         timer.start("cbca_iter_prog_pair")
-        hip.check(lib.mccnn_cbca_iter_prog_pair(hip.ptr(sl), hip.ptr(dl), hip.ptr(support_l), hip.ptr(progs[0]), hip.ptr(sr),
-                                                hip.ptr(dr), hip.ptr(support_r), hip.ptr(progs[1]), int(D), H, W,
-                                                int(distance_threshold), hip.stream()), "mccnn_cbca_iter_prog_pair")
+        if wta_out is not None and it == n - 1:
+            for t in wta_out:
+                if tuple(t.shape) != (H, W) or t.dtype != torch.float32 or not t.is_contiguous():
+                    raise ValueError("cbca_prog_pair: wta_out must be two contiguous float32 [H,W] tensors")
+            hip.check(lib.mccnn_cbca_iter_prog_pair_wta(hip.ptr(sl), hip.ptr(dl), hip.ptr(support_l), hip.ptr(progs[0]),
+                                                        hip.ptr(sr), hip.ptr(dr), hip.ptr(support_r), hip.ptr(progs[1]),
+                                                        int(D), H, W, int(distance_threshold), hip.ptr(wta_out[0]),
+                                                        hip.ptr(wta_out[1]), 1 if store_right else 0, hip.stream()),
+                      "mccnn_cbca_iter_prog_pair_wta")
+        else:
+            hip.check(lib.mccnn_cbca_iter_prog_pair(hip.ptr(sl), hip.ptr(dl), hip.ptr(support_l), hip.ptr(progs[0]),
+                                                    hip.ptr(sr), hip.ptr(dr), hip.ptr(support_r), hip.ptr(progs[1]), int(D),
+                                                    H, W, int(distance_threshold), hip.stream()),
+                      "mccnn_cbca_iter_prog_pair")
         timer.stop()
         sl, dl, sr, dr = dl, sl, dr, sr
     return (sl, dl), (sr, dr)
@@ -753,17 +769,10 @@ class StereoMatcher(object):
             progs = ws["progs"]
 
             def aggregate_hwd(lh, lt, rh, rt, n, **kw):
-                # the program-driven assembly kernel where its programs exist; an iteration that also carries the WTA
-                # is cbca_hwd_kernel's (same bits either way)
-                n = int(n)
-                tail = 1 if (kw.get("wta_out") is not None and n >= 1) else 0
+                # the program-driven assembly kernel where its programs exist, cbca_hwd_kernel otherwise (same bits)
                 if progs is None:
-                    return cbca_hwd_pair(lh, lt, sup_l, rh, rt, sup_r, D, n, hp["cbca_distance"], timer, **kw)
-                (lh, lt), (rh, rt) = cbca_prog_pair(lh, lt, sup_l, rh, rt, sup_r, progs, D, n - tail, hp["cbca_distance"],
-                                                    timer)
-                if tail:
-                    return cbca_hwd_pair(lh, lt, sup_l, rh, rt, sup_r, D, 1, hp["cbca_distance"], timer, **kw)
-                return (lh, lt), (rh, rt)
+                    return cbca_hwd_pair(lh, lt, sup_l, rh, rt, sup_r, D, int(n), hp["cbca_distance"], timer, **kw)
+                return cbca_prog_pair(lh, lt, sup_l, rh, rt, sup_r, progs, D, int(n), hp["cbca_distance"], timer, **kw)
 
             (lh, lt), (rh, rt) = aggregate_hwd(lh, as_hwd(b0), rh, as_hwd(b1), hp["cbca_num_iterations1"])
             if keep is not None:

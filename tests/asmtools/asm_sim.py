@@ -66,6 +66,7 @@ def f2u(x):
 class Wave:
     def __init__(self, gen, mem, code_addr=0x7e00fffff000):
         self.ins = [i for i in gen.ins]
+        self.P = gen.P
         self.mem = mem
         self.code_addr = code_addr
         # byte offset -> instruction index; label -> index
@@ -258,6 +259,24 @@ class Wave:
                 if self.pending and False:
                     raise SimError("loads in flight at s_endpgm")
                 return self.stats
+            elif op == "pseudo_wta":
+                # the fused WTA tail (cbca_prog_gen.py wta_tail), evaluated as pf:245-254 states it
+                from cbca_prog_gen import S as SR
+                P = self.P
+                D, H, W = self.s[SR["D"]], self.s[SR["H"]], self.s[SR["W"]]
+                y0, x0 = self.s[SR["y0"]], self.s[SR["x0"]]
+                base = self.s[SR["dispp"]] | (self.s[SR["dispp"] + 1] << 32)
+                for k in range(P.K):
+                    for j in range(P.G):
+                        vals = np.stack([f32(self.v[P.acc(k, j, c)]) for c in range(P.VPL)], axis=1)   # [lane, c]
+                        d = (np.arange(64)[:, None] * P.VPL + np.arange(P.VPL)[None, :])
+                        best, bd = np.inf, -1
+                        for dd, vv in sorted(zip(d.reshape(-1).tolist(), vals.reshape(-1).tolist())):
+                            if dd < D and vv < best:
+                                best, bd = vv, int(dd)
+                        if y0 + k < H and x0 + j < W:
+                            self.mem.write(base + ((y0 + k) * W + x0 + j) * 4, np.array([bd], np.float32).view(np.uint8))
+                self.stats["valu"] += int(a[1])
             elif op == "pseudo_rcp":
                 dst, den, skip = a
                 d = self.vrange(den)[0]

@@ -179,6 +179,53 @@ def test_generated_kernel_with_scalar_prefetch_in_the_simulator():
         assert np.array_equal(got, oracle_cbca(img, vol))
 
 
+def test_generated_wta_kernel_in_the_simulator(tmp_path):
+    """The last-iteration kernel (aggregation + a7's first strict minimum): its aggregation part runs in the simulator
+    like the plain kernel's, its reduction tail is evaluated as pf:245-254 states it; the assembler accepts the tail and
+    the size model still holds (the tail's DPP instructions are 8 bytes)."""
+    g = gen.Gen(gen.Params(vpl=4, K=4, W=20, wta=True)).build()
+    s = tmp_path / "k.s"
+    s.write_text(g.render())
+    if os.path.exists(os.path.join(LLVM, "clang")):
+        obj = tmp_path / "k.o"
+        subprocess.check_call([os.path.join(LLVM, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa",
+                               "-mcpu=gfx950", "-c", str(s), "-o", str(obj)])
+        dis = subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", str(obj)]).decode()
+        ends = [int(ln.split("//")[1].split(":")[0].strip(), 16) for ln in dis.splitlines() if "s_endpgm" in ln]
+        assert ends == [g.offsets()["done"]]
+    L = g.layout()
+    plain = gen.Gen(gen.Params(vpl=4, K=4, W=20)).build().layout()
+    assert all(L[k] == plain[k] for k in ("add", "load", "wait", "refill", "end")), "one set of programs serves both kernels"
+    img, vol = make_case(11, 14, 7, 3)
+    D, H, W = vol.shape
+    sup0 = support_words(img)
+    progs, meta = ref.build_all(sup0, H, W, L)
+    Dp = 8
+    hwd = np.zeros((H, W, Dp), np.float32)
+    hwd[:, :, :D] = vol.transpose(1, 2, 0)
+    mem = asm_sim.Memory()
+    a_in, a_out = mem.alloc(hwd), mem.alloc(np.full((H, W, Dp), np.nan, np.float32))
+    a_prog = mem.alloc(progs)
+    a_sup = mem.alloc(np.concatenate([sup0.reshape(-1), np.zeros(64, np.uint32)]))
+    a_disp = mem.alloc(np.full((H, W), -7.0, np.float32))
+    karg = np.zeros(0x80 // 4, np.uint32)
+    for i, v in ((0, a_in), (2, a_in), (4, a_out), (6, a_out), (8, a_prog), (10, a_prog), (12, a_sup), (14, a_sup),
+                 (24, a_disp), (26, a_disp)):
+        karg[i], karg[i + 1] = v & 0xffffffff, v >> 32
+    karg[16:24] = [Dp, H, W, 1, meta["band_rows"], meta["band_groups"], meta["stride"] * 4, meta["ngroups"]]
+    karg[28], karg[29] = D, 1
+    a_k = mem.alloc(karg)
+    wave = asm_sim.Wave(g, mem)
+    for bx in range(8 * meta["band_groups"]):
+        for by in range(meta["ngroups"]):
+            wave.run({0: a_k & 0xffffffff, 1: a_k >> 32, 2: bx, 3: by, 4: 0}, np.arange(64, dtype=np.uint32), g.P.nvgpr)
+    want = oracle_cbca(img, vol)
+    got = mem.get(a_out, np.float32, H * W * Dp).reshape(H, W, Dp)[:, :, :D].transpose(2, 0, 1)
+    assert np.array_equal(got, want)
+    disp = mem.get(a_disp, np.float32, H * W).reshape(H, W)
+    assert np.array_equal(disp, np.argmin(want, axis=0).astype(np.float32))
+
+
 def test_simulated_kernel_special_values_and_code_address_carry():
     """inf / NaN / signed zeros travel through the add chains like through the reference's running sum; the code base
     sits right below a 4 GiB boundary so that the dispatcher's 64-bit address arithmetic carries."""
