@@ -117,10 +117,11 @@ def ins_size(i):
 
 
 class Params:
-    def __init__(self, vpl=4, K=2, G=5, W=12, NB=1, PF=0, wta=False, debug=0):
+    def __init__(self, vpl=4, K=2, G=5, W=12, NB=1, PF=0, wta=False, debug=0, order=0):
         assert K in (1, 2, 4, 8), "anchor sets are aligned power-of-two groups of anchor rows"
         assert K * G <= 20, "the region sizes of the K x G anchors live in s[16:35]"
         self.VPL, self.K, self.G, self.W, self.NB, self.PF, self.wta, self.debug = vpl, K, G, W, NB, PF, wta, debug
+        self.order = order                          # 0: column-group-major dispatch inside an XCD's band, 1: row-group-major
         self.MAXD = min(W, R + 1)                   # longest descending run one op can carry (self + left arm)
         self.MAXA = min(W, R)                       # longest ascending run
         self.RS = vpl + (vpl & 1)                   # registers per slot / accumulator: gfx950 wants even-aligned tuples
@@ -249,7 +250,12 @@ class Gen:
         e("s_waitcnt", "lgkmcnt(0)")
         # y0 = (bx & 7) * band_rows + (bx >> 3) * K ; patch row group = (bx & 7) * band_groups + (bx >> 3)
         e("s_and_b32", s("t0"), s("bx"), 7)
-        e("s_lshr_b32", s("t1"), s("bx"), 3)
+        if P.order == 0:      # an XCD sweeps its band column group by column group: x = (band, row group), y = column group
+            e("s_lshr_b32", s("t1"), s("bx"), 3)
+            e("s_mov_b32", s("t3"), s("by"))
+        else:                 # ... row group by row group: x = (band, column group), y = row group
+            e("s_lshr_b32", s("t3"), s("bx"), 3)
+            e("s_mov_b32", s("t1"), s("by"))
         e("s_mul_i32", s("y0"), s("t0"), s("band_rows"))
         e("s_mul_i32", s("t2"), s("t1"), K)
         e("s_add_u32", s("y0"), s("y0"), s("t2"))
@@ -258,8 +264,8 @@ class Gen:
         e("s_mul_i32", s("t0"), s("t0"), s("band_groups"))
         e("s_add_u32", s("t0"), s("t0"), s("t1"))                        # patch row group
         e("s_mul_i32", s("t0"), s("t0"), s("ngroups"))
-        e("s_add_u32", s("t0"), s("t0"), s("by"), comment="patch index")
-        e("s_mul_i32", s("x0"), s("by"), G)
+        e("s_add_u32", s("t0"), s("t0"), s("t3"), comment="patch index")
+        e("s_mul_i32", s("x0"), s("t3"), G)
         # job = bz >= nchunks, chunk = bz - job * nchunks; pick the job's pointers
         e("s_cmp_ge_u32", s("bz"), s("nchunks"))
         e("s_cselect_b32", s("job"), 1, 0)
@@ -683,13 +689,14 @@ def main():
     ap.add_argument("--vpl", type=int, default=4)
     ap.add_argument("--w", type=int, default=12)
     ap.add_argument("--k", type=int, default=2)
+    ap.add_argument("--order", type=int, default=0)
     ap.add_argument("--nb", type=int, default=1)
     ap.add_argument("--pf", type=int, default=0)
     ap.add_argument("--wta", action="store_true")
     ap.add_argument("-o", default=None)
     ap.add_argument("--header", default=None)
     a = ap.parse_args()
-    P = Params(vpl=a.vpl, K=a.k, W=a.w, NB=a.nb, PF=a.pf, wta=a.wta)
+    P = Params(vpl=a.vpl, K=a.k, W=a.w, NB=a.nb, PF=a.pf, wta=a.wta, order=a.order)
     g = Gen(P).build()
     if a.o:
         open(a.o, "w").write(g.render())

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
     // A fragments: slot ks % NSLOT, fetched NSLOT - 1 K steps ahead (the weights are the same for every tile, so the
     // stream simply wraps).  vmcnt counts in order: the activation pieces fetched at the start of a channel group
     // have to land before the first A fragment issued after them is needed, i.e. within NSLOT - 1 K steps.
-    constexpr int NSLOT = 4;
+    constexpr int NSLOT = MODE == 0 ? 3 : 4;     // (MODE 0 has the heavier epilogue: with four slots and the second accumulator set it spills)
     w4 af[NSLOT][4];
     auto fetch_a = [&](int slot, int ks) {
 #pragma unroll
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
 
         // ---- epilogue: this wave's four rows of 32 pixels ----
         const int px = lane & 31, half = lane >> 5;
-        bool sat = false;
+        int satbits = 0;
 #ifdef CONV_ABL_NOEPI   // timing experiment: one store per accumulator so the MFMAs stay live
         {
             float t = 0.f;
@@ -361,9 +361,8 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
                 for (int r = 0; r < 16; ++r) {
                     const int ch = 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * half;
                     if (MODE == 0) {
-                        const float t = fmaf(acc[nb][mb][r] + accx[nb][mb][r], inv_scale * act_scale, bias[ch] * act_scale);
-                        sat |= !(t <= 65504.f);                       // also true for NaN
-                        y[mb][r] = __builtin_amdgcn_fmed3f(t, 0.f, 65504.f);
+                        // computed where it is split and stored (below): 32 live registers fewer - with the second
+                        // accumulator set this kernel otherwise spills
                     } else {
                         const float t = fmaf(acc[nb][mb][r] + accx[nb][mb][r], inv_scale, bias[ch]);
                         y[mb][r] = t;
@@ -391,7 +390,18 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
                             const int ch = 32 * mb + 8 * g + 4 * half;          // first of 4 consecutive maps
                             if (MODE == 0) {
                                 w2 hi, lo;
-                                split4_scaled(&y[mb][4 * g], hi, lo);
+                                float y4[4];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const int r = 4 * g + q;
+                                    const float t = fmaf(acc[nb][mb][r] + accx[nb][mb][r], inv_scale * act_scale,
+                                                         bias[ch + q] * act_scale);
+                                    // largest value seen, compared as integers (positive floats order like their bit
+                                    // patterns, negative ones are negative integers, a NaN is above every finite value)
+                                    satbits = max(satbits, __float_as_int(t));
+                                    y4[q] = __builtin_amdgcn_fmed3f(t, 0.f, 65504.f);
+                                }
+                                split4_scaled(y4, hi, lo);
                                 char *p = epi + pl * EPITCH + (ch >> 4) * 64 + (ch & 15) * 2;
                                 *reinterpret_cast<w2 *>(p) = hi;
                                 *reinterpret_cast<w2 *>(p + 32) = lo;
@@ -421,7 +431,8 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
         }
         // a stored activation left the f16 range of the records (|x| * act_scale > 65504): the clamp keeps the data
         // finite, the flag tells the host that this pair's features are not float32-accurate (mccnn.h)
-        if (MODE == 0 && sat_flag && __builtin_amdgcn_ballot_w64(sat) != 0 && lane == 0) atomicOr(sat_flag, 1);
+        if (MODE == 0 && sat_flag && __builtin_amdgcn_ballot_w64(satbits > __float_as_int(65504.f)) != 0 && lane == 0)
+            atomicOr(sat_flag, 1);
 #endif
         if (vn >= total) break;
         v = vn;

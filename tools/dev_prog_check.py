@@ -120,7 +120,7 @@ def main():
     ap.add_argument("--w", type=int, default=12); ap.add_argument("--small-only", action="store_true")
     ap.add_argument("--nb", type=int, default=1); ap.add_argument("--skip-small", action="store_true")
     ap.add_argument("--experiments", action="store_true"); ap.add_argument("--pf", default="")
-    ap.add_argument("--k", type=int, default=2)
+    ap.add_argument("--k", type=int, default=2); ap.add_argument("--order", type=int, default=0)
     args = ap.parse_args()
     global K_DEFAULT
     K_DEFAULT = args.k
@@ -180,6 +180,19 @@ def main():
         ok = torch.equal(b, want_l) and torch.equal(d, want_r)
         ms = timeit(lambda: m2.launch((8 * meta["band_groups"], meta["ngroups"], nchunks * 2), ka), args.iters)
         print("  scalar prefetch %2d columns ahead: %8.4f ms  bit-exact %s" % (pf, ms, ok), flush=True)
+    if args.order:
+        g2 = gen.Gen(gen.Params(vpl=vpl, K=args.k, W=args.w, NB=args.nb, order=1)).build()
+        base = os.path.join(ROOT, "mc-cnn-python_amd", "build", "asm", "cbca_prog_order1")
+        open(base + ".s", "w").write(g2.render())
+        subprocess.check_call([LLVM + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", base + ".s", "-o", base + ".o"])
+        subprocess.check_call([LLVM + "/ld.lld", "-shared", base + ".o", "-o", base + ".hsaco"])
+        m2 = Module(base + ".hsaco", g2.P.name())
+        grid1 = (8 * meta["ngroups"], meta["band_groups"], nchunks * 2)
+        b.fill_(float("nan")); d.fill_(float("nan"))
+        m2.launch(grid1, ka); torch.cuda.synchronize()
+        ok = torch.equal(b, want_l) and torch.equal(d, want_r)
+        ms = timeit(lambda: m2.launch(grid1, ka), args.iters)
+        print("  row-group-major dispatch: %8.4f ms  bit-exact %s" % (ms, ok), flush=True)
     if args.experiments:
         grid = (8 * meta["band_groups"], meta["ngroups"], nchunks * 2)
         for lds in (20480, 40960, 81920):
