@@ -117,7 +117,7 @@ def ins_size(i):
 
 
 class Params:
-    def __init__(self, vpl=4, K=2, G=5, W=12, NB=1, PF=0, wta=False, debug=0, order=0):
+    def __init__(self, vpl=4, K=2, G=5, W=12, NB=1, PF=0, wta=False, debug=0, order=0, minvgpr=0):
         assert K in (1, 2, 4, 8), "anchor sets are aligned power-of-two groups of anchor rows"
         assert K * G <= 20, "the region sizes of the K x G anchors live in s[16:35]"
         self.VPL, self.K, self.G, self.W, self.NB, self.PF, self.wta, self.debug = vpl, K, G, W, NB, PF, wta, debug
@@ -131,6 +131,7 @@ class Params:
         self.PHYS_WIN = max(self.nacc + 4, self.RS * (self.MAXA - 1))
         self.PHYS_WIN = (self.PHYS_WIN + 3) & ~3
         self.nvgpr = self.PHYS_WIN + NB * W * self.RS      # NB windows: the next one loads under the current one's adds
+        self.nvgpr_alloc = max(self.nvgpr, minvgpr)        # experiments: a larger allocation = fewer waves per SIMD
         self.NWAIT = W + 1                          # WAIT handlers 0 .. W
 
     def acc(self, k, j, c=0):
@@ -290,6 +291,19 @@ class Gen:
         e("buffer_load_dword", vreg(P.v_progA), vreg(P.v_lane4), s("rs_prog", 4), 0, offen=True)
         e("buffer_load_dword", vreg(P.v_progB), vreg(P.v_lane4), s("rs_prog", 4), 0, offen=True, offset=256)
         e("s_movk_i32", s("progoff"), 512)
+        # region sizes of the K x G anchors for the END handler (rows clamped to the image; words past the right edge are
+        # never used), requested here so that they arrive under the program: the kernarg registers they land in are dead
+        e("s_sub_u32", s("t3"), s("H"), 1)
+        for k in range(K):
+            e("s_add_u32", s("t0"), s("y0"), k)
+            e("s_min_i32", s("t0"), s("t0"), s("t3"))
+            e("s_mul_i32", s("t0"), s("t0"), s("W"))
+            e("s_add_u32", s("t0"), s("t0"), s("x0"))
+            e("s_lshl_b32", s("t0"), s("t0"), 2)                            # H * W * 4 < 2^31 (checked by the host)
+            e("s_add_u32", s("t4"), s("supp"), s("t0"))
+            e("s_addc_u32", s("t5"), sreg(S["supp"] + 1), 0)
+            for j in range(G):
+                e("s_load_dword", sreg(S["cnt"] + k * G + j), sreg(S["t4"], 2), 4 * j)
         # pix = Dp * 4 ; voff = d0 * 4 with d0 = (chunk * 64 + lane) * VPL, or kDrop past the disparity range
         e("s_lshl_b32", s("pix"), s("Dp"), 2)
         e("s_lshl_b32", s("t1"), s("chunk"), 6)
@@ -390,19 +404,7 @@ class Gen:
         # ---- END: pf:161 -------------------------------------------------------------------------------------------------------
         self.label("end")
         e("s_set_gpr_idx_off")
-        # region sizes of the K x G anchors (rows clamped to the image; words past the right edge are never used)
-        e("s_sub_u32", s("t3"), s("H"), 1)
-        for k in range(K):
-            e("s_add_u32", s("t0"), s("y0"), k)
-            e("s_min_i32", s("t0"), s("t0"), s("t3"))
-            e("s_mul_i32", s("t0"), s("t0"), s("W"))
-            e("s_add_u32", s("t0"), s("t0"), s("x0"))
-            e("s_lshl_b32", s("t0"), s("t0"), 2)                            # H * W * 4 < 2^31 (checked by the host)
-            e("s_add_u32", s("t4"), s("supp"), s("t0"))
-            e("s_addc_u32", s("t5"), sreg(S["supp"] + 1), 0)
-            for j in range(G):
-                e("s_load_dword", sreg(S["cnt"] + k * G + j), sreg(S["t4"], 2), 4 * j)
-        e("s_waitcnt", "lgkmcnt(0)")
+        e("s_waitcnt", "lgkmcnt(0)", comment="the region sizes, requested in the prologue")
         T = P.PHYS_WIN                                                  # the window is dead: temporaries
         assert P.W * P.RS >= 1 + 5 * VPL, "the division's temporaries live in the window registers"
         # pf:161 sum / n, correctly rounded like NumPy's float32 division: the compiler's own sequence (v_div_scale x 2,
@@ -640,15 +642,15 @@ class Gen:
                 "  .amdhsa_kernarg_size %d" % kargs, "  .amdhsa_user_sgpr_count 2",
                 "  .amdhsa_user_sgpr_kernarg_segment_ptr 1", "  .amdhsa_system_sgpr_workgroup_id_x 1",
                 "  .amdhsa_system_sgpr_workgroup_id_y 1", "  .amdhsa_system_sgpr_workgroup_id_z 1",
-                "  .amdhsa_system_vgpr_workitem_id 0", "  .amdhsa_next_free_vgpr %d" % P.nvgpr,
-                "  .amdhsa_next_free_sgpr %d" % NSGPR, "  .amdhsa_accum_offset %d" % ((P.nvgpr + 3) & ~3),
+                "  .amdhsa_system_vgpr_workitem_id 0", "  .amdhsa_next_free_vgpr %d" % P.nvgpr_alloc,
+                "  .amdhsa_next_free_sgpr %d" % NSGPR, "  .amdhsa_accum_offset %d" % ((P.nvgpr_alloc + 3) & ~3),
                 "  .amdhsa_reserve_vcc 1", "  .amdhsa_float_round_mode_32 0", "  .amdhsa_float_round_mode_16_64 0",
                 "  .amdhsa_float_denorm_mode_32 3", "  .amdhsa_float_denorm_mode_16_64 3", "  .amdhsa_dx10_clamp 1",
                 "  .amdhsa_ieee_mode 1", ".end_amdhsa_kernel", "",
                 ".amdgpu_metadata", "---", "amdhsa.version:", "  - 1", "  - 2", "amdhsa.kernels:",
                 "  - .name: %s" % name, "    .symbol: %s.kd" % name, "    .kernarg_segment_size: %d" % kargs,
                 "    .kernarg_segment_align: 8", "    .group_segment_fixed_size: 0", "    .private_segment_fixed_size: 0",
-                "    .wavefront_size: 64", "    .sgpr_count: %d" % (NSGPR + 6), "    .vgpr_count: %d" % P.nvgpr,
+                "    .wavefront_size: 64", "    .sgpr_count: %d" % (NSGPR + 6), "    .vgpr_count: %d" % P.nvgpr_alloc,
                 "    .agpr_count: 0", "    .max_flat_workgroup_size: 64", "    .args:"]
         off = 0
         while off < kargs:
@@ -693,10 +695,11 @@ def main():
     ap.add_argument("--nb", type=int, default=1)
     ap.add_argument("--pf", type=int, default=0)
     ap.add_argument("--wta", action="store_true")
+    ap.add_argument("--minvgpr", type=int, default=0, help="experiments: allocate at least this many VGPRs (occupancy)")
     ap.add_argument("-o", default=None)
     ap.add_argument("--header", default=None)
     a = ap.parse_args()
-    P = Params(vpl=a.vpl, K=a.k, W=a.w, NB=a.nb, PF=a.pf, wta=a.wta, order=a.order)
+    P = Params(vpl=a.vpl, K=a.k, W=a.w, NB=a.nb, PF=a.pf, wta=a.wta, order=a.order, minvgpr=a.minvgpr)
     g = Gen(P).build()
     if a.o:
         open(a.o, "w").write(g.render())

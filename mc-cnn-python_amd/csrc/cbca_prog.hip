@@ -48,7 +48,13 @@ static const char *const kName[2][3] = {{"mccnn_cbca_prog_v2", "mccnn_cbca_prog_
 
 // disparities per lane: 2 up to 128, 3 where that fills the lanes exactly (padded D a multiple of 3 up to 192), else 4
 // with 256-disparity chunks - the same rule as cbca_hwd.hip
-static int vpl_of(int Dp) { return Dp <= 128 ? 2 : (Dp <= 192 && Dp % 3 == 0) ? 3 : 4; }
+static int vpl_of(int Dp)
+{
+#ifdef MCCNN_PROG_FORCE_VPL      // experiments (tools/build_prog_variant.sh): e.g. 256 disparities as two 128-disparity chunks
+    return MCCNN_PROG_FORCE_VPL;
+#endif
+    return Dp <= 128 ? 2 : (Dp <= 192 && Dp % 3 == 0) ? 3 : 4;
+}
 
 struct Loaded {
     hipModule_t mod = nullptr;

@@ -424,6 +424,55 @@ __global__ __launch_bounds__(64) void cost_volume_fill_hwd_kernel(float *__restr
     }
 }
 
+
+// The same recurrences with ONE disparity per lane: a wave owns 64 consecutive disparities of one image row and side,
+// so a row has Dp / 64 waves instead of one (cfg2: 4000 waves instead of 1000 - the four-per-lane form above is one
+// wave per SIMD walking D + 2 dependent 1 KiB loads, 0.13 ms of latency for 34 M entries), each sweeping only the
+// columns its own disparities touch (chunk q: 64 q + 66 of them), 16 loads in flight.  Same float32 operations in the
+// same order per entry as cost_volume_fill_hwd_kernel (and as the plane-major fill kernel): bit-identical.
+__global__ __launch_bounds__(64) void cost_volume_fill_hwd_lanes_kernel(float *__restrict__ lcv, float *__restrict__ rcv,
+                                                                        int D, int Dp, int H, int W)
+{
+    constexpr int PF = 16;
+    constexpr int kDrop = 0x7ffffff0;
+    const int lane = threadIdx.x, h = blockIdx.x;
+    const bool left = blockIdx.y == 0;
+    const int d = (int)blockIdx.z * 64 + lane;
+    const int dmax = min((int)blockIdx.z * 64 + 63, D - 1);       // the largest disparity of this wave that exists
+    if ((int)blockIdx.z * 64 >= D) return;
+    float *row = (left ? lcv : rcv) + (size_t)h * W * Dp;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(row, 0, (int)((size_t)W * Dp * 4), 0x00020000);
+    const unsigned pix = (unsigned)Dp * 4u;
+    const int c_first = left ? dmax + 2 : max(W - dmax - 3, 0), nsteps = left ? c_first + 1 : W - c_first;
+    auto col = [&](int t) { return left ? c_first - t : c_first + t; };
+    const int voff = d < Dp ? d * 4 : kDrop;
+    float x1 = 0.f, x2 = 0.f, x3 = 0.f;
+    float buf[PF];
+    auto issue = [&](int slot, int t) {
+        buf[slot] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, (unsigned)col(min(t, nsteps - 1)) * pix, 0));
+    };
+#pragma unroll
+    for (int k = 0; k < PF; ++k) issue(k, k);
+    for (int t0 = 0; t0 < nsteps; t0 += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int t = t0 + k;
+            if (t >= nsteps) continue;
+            const int c = col(t);
+            const bool stored = left ? c >= d : c < W - d;         // the score itself (d >= D: pad, never used)
+            float s = 0.f + x1;
+            s = s + x2;
+            s = s + x3;
+            const float val = stored ? buf[k] : s / 3.f;
+            if (left) { x3 = x2; x2 = x1; x1 = val; }               // x1 = column c + 1 next
+            else      { x1 = x2; x2 = x3; x3 = val; }               // x3 = column c - 1 next
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rs, (!stored && d < D) ? voff : kDrop,
+                                                  (unsigned)c * pix, 0);
+            issue(k, t + PF);
+        }
+    }
+}
+
 }  // namespace mccnn
 
 extern "C" int mccnn_cost_volume(const float *fl, const float *fr, int H, int W, int C, int D, float *lcv, float *rcv,
@@ -480,10 +529,15 @@ extern "C" int mccnn_cost_volume_hwd(const float *fl, const float *fr, int H, in
     int rc = check_launch("mccnn_cost_volume_hwd");
     if (rc) return rc;
     if (D > 1) {
+#ifdef CV_FILL_FOUR_PER_LANE     // A/B builds: the four-disparities-per-lane sweep (one wave per row and side)
         if (Dp <= 256)
             hipLaunchKernelGGL(cost_volume_fill_hwd_kernel<1>, dim3(H, 2), dim3(64), 0, s, lcv_hwd, rcv_hwd, D, Dp, H, W);
         else
             hipLaunchKernelGGL(cost_volume_fill_hwd_kernel<2>, dim3(H, 2), dim3(64), 0, s, lcv_hwd, rcv_hwd, D, Dp, H, W);
+#else
+        hipLaunchKernelGGL(cost_volume_fill_hwd_lanes_kernel, dim3(H, 2, cdiv(D, 64)), dim3(64), 0, s, lcv_hwd, rcv_hwd, D, Dp,
+                           H, W);
+#endif
     }
     return check_launch("mccnn_cost_volume_hwd(fill)");
 }
