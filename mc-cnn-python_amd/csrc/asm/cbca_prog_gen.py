@@ -117,11 +117,16 @@ def ins_size(i):
 
 
 class Params:
-    def __init__(self, vpl=4, K=2, G=5, W=12, NB=1, PF=0, wta=False, debug=0, order=0, minvgpr=0):
+    def __init__(self, vpl=4, K=2, G=5, W=12, NB=1, PF=0, wta=False, debug=0, order=0, minvgpr=0, skip=False):
         assert K in (1, 2, 4, 8), "anchor sets are aligned power-of-two groups of anchor rows"
         assert K * G <= 20, "the region sizes of the K x G anchors live in s[16:35]"
         self.VPL, self.K, self.G, self.W, self.NB, self.PF, self.wta, self.debug = vpl, K, G, W, NB, PF, wta, debug
         self.order = order                          # 0: column-group-major dispatch inside an XCD's band, 1: row-group-major
+        # skip: the kernel for the "skip" programs (cbca_prog_build.h, unit_region): an anchor whose support region is the
+        # pixel itself - all four arms 0 in its support word - is neither divided nor stored (its value already stands in
+        # the output buffer: the caller's promise, include/mccnn.h)
+        self.skip = skip
+        assert not (skip and wta), "the last iteration needs every pixel's values for the WTA: it runs the full programs"
         self.MAXD = min(W, R + 1)                   # longest descending run one op can carry (self + left arm)
         self.MAXA = min(W, R)                       # longest ascending run
         self.RS = vpl + (vpl & 1)                   # registers per slot / accumulator: gfx950 wants even-aligned tuples
@@ -146,7 +151,7 @@ class Params:
         return out
 
     def name(self):
-        return "mccnn_cbca_prog_v%d%s" % (self.VPL, "_wta" if self.wta else "")
+        return "mccnn_cbca_prog_v%d%s" % (self.VPL, "_wta" if self.wta else "_skip" if self.skip else "")
 
 
 # ---- scalar register map ------------------------------------------------------------------------------------------
@@ -418,6 +423,9 @@ class Gen:
         pairs = [S["t0"], S["t2"], S["t4"], S["dump"]]                  # SGPR pairs for the components' scale flags
         for k in range(K if not (P.debug & 1) else 0):               # debug 1: raw sums instead of quotients
             for j in range(G):
+                if P.skip:
+                    e("s_and_b32", s("t0"), sreg(S["cnt"] + k * G + j), 0xfffff, comment="all four arms 0: not this kernel's pixel")
+                    e("s_cbranch_scc0", "nodiv_%d_%d" % (k, j))
                 e("s_lshr_b32", s("t0"), sreg(S["cnt"] + k * G + j), 20)
                 e("v_cvt_f32_u32", vreg(den), s("t0"))
                 C = range(VPL)
@@ -449,6 +457,8 @@ class Gen:
                     e("v_div_fmas_f32", vreg(tmp(c, A)), vreg(tmp(c, A)), vreg(tmp(c, Rr)), vreg(tmp(c, Q)), sim_skip=True)
                 for c in C:
                     e("v_div_fixup_f32", vreg(num(c)), vreg(tmp(c, A)), vreg(den), vreg(num(c)), sim_skip=True)
+                if P.skip:
+                    self.label("nodiv_%d_%d" % (k, j))
         # stores: per anchor row a descriptor that ends with the row / the image (columns past the edge are dropped)
         e("s_sub_u32", s("t5"), s("W"), s("x0"))
         e("s_min_i32", s("t5"), s("t5"), G)
@@ -474,8 +484,13 @@ class Gen:
             for j in range(G):
                 pol = {0: dict(nt=True), 4: {}, 8: dict(sc1=True), 12: dict(sc0=True, sc1=True), 16: dict(sc1=True, nt=True),
                        20: dict(sc0=True, sc1=True, nt=True)}[P.debug & 28]      # debug 4..20: other cache policies
+                if P.skip:
+                    e("s_and_b32", s("t0"), sreg(S["cnt"] + k * G + j), 0xfffff)
+                    e("s_cbranch_scc0", "nostore_%d_%d" % (k, j))
                 self.vstore(P.acc(k, j), P.v_voff, S["rs_out"], s("so"), **pol)
                 e("s_nop", 0, comment="gfx950 store-data hazard (common.h)")
+                if P.skip:
+                    self.label("nostore_%d_%d" % (k, j))
                 if j + 1 < G:
                     e("s_add_u32", s("so"), s("so"), s("pix"))
         if P.wta:
@@ -633,7 +648,7 @@ class Gen:
             else:
                 line = i.render()
                 # local labels: branch targets and the code_base difference
-                line = re.sub(r"\b(code_base|after_getpc|done|pf_done|pf_loop\d+|load_b\d+_blk\d+)\b", lambda m: ".L%s_%s" % (name, m.group(1)), line)
+                line = re.sub(r"\b(code_base|after_getpc|done|pf_done|pf_loop\d+|load_b\d+_blk\d+|nodiv_\d+_\d+|nostore_\d+_\d+)\b", lambda m: ".L%s_%s" % (name, m.group(1)), line)
                 out.append(line)
         kargs = 0x80 if P.wta else 0x60
         out += [".Lfunc_end_%s:" % name, ".size %s, .Lfunc_end_%s-%s" % (name, name, name), "",
@@ -695,11 +710,12 @@ def main():
     ap.add_argument("--nb", type=int, default=1)
     ap.add_argument("--pf", type=int, default=0)
     ap.add_argument("--wta", action="store_true")
+    ap.add_argument("--skip", action="store_true", help="the kernel of the skip programs (unit regions neither divided nor stored)")
     ap.add_argument("--minvgpr", type=int, default=0, help="experiments: allocate at least this many VGPRs (occupancy)")
     ap.add_argument("-o", default=None)
     ap.add_argument("--header", default=None)
     a = ap.parse_args()
-    P = Params(vpl=a.vpl, K=a.k, W=a.w, NB=a.nb, PF=a.pf, wta=a.wta, order=a.order, minvgpr=a.minvgpr)
+    P = Params(vpl=a.vpl, K=a.k, W=a.w, NB=a.nb, PF=a.pf, wta=a.wta, order=a.order, minvgpr=a.minvgpr, skip=a.skip)
     g = Gen(P).build()
     if a.o:
         open(a.o, "w").write(g.render())

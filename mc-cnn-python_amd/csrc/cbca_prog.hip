@@ -41,10 +41,22 @@ alignas(4096) static const unsigned char kCodeV3w[] = {
 alignas(4096) static const unsigned char kCodeV4w[] = {
 #include "cbca_prog_v4w.inc"
 };
-// [with WTA][disparities per lane - 2]
-static const unsigned char *const kCode[2][3] = {{kCodeV2, kCodeV3, kCodeV4}, {kCodeV2w, kCodeV3w, kCodeV4w}};
-static const char *const kName[2][3] = {{"mccnn_cbca_prog_v2", "mccnn_cbca_prog_v3", "mccnn_cbca_prog_v4"},
-                                        {"mccnn_cbca_prog_v2_wta", "mccnn_cbca_prog_v3_wta", "mccnn_cbca_prog_v4_wta"}};
+alignas(4096) static const unsigned char kCodeV2s[] = {
+#include "cbca_prog_v2s.inc"
+};
+alignas(4096) static const unsigned char kCodeV3s[] = {
+#include "cbca_prog_v3s.inc"
+};
+alignas(4096) static const unsigned char kCodeV4s[] = {
+#include "cbca_prog_v4s.inc"
+};
+// [kernel: 0 plain, 1 with WTA, 2 skip][disparities per lane - 2]
+enum { kPlain = 0, kWta = 1, kSkip = 2 };
+static const unsigned char *const kCode[3][3] = {{kCodeV2, kCodeV3, kCodeV4}, {kCodeV2w, kCodeV3w, kCodeV4w},
+                                                 {kCodeV2s, kCodeV3s, kCodeV4s}};
+static const char *const kName[3][3] = {{"mccnn_cbca_prog_v2", "mccnn_cbca_prog_v3", "mccnn_cbca_prog_v4"},
+                                        {"mccnn_cbca_prog_v2_wta", "mccnn_cbca_prog_v3_wta", "mccnn_cbca_prog_v4_wta"},
+                                        {"mccnn_cbca_prog_v2_skip", "mccnn_cbca_prog_v3_skip", "mccnn_cbca_prog_v4_skip"}};
 
 // disparities per lane: 2 up to 128, 3 where that fills the lanes exactly (padded D a multiple of 3 up to 192), else 4
 // with 256-disparity chunks - the same rule as cbca_hwd.hip
@@ -60,22 +72,22 @@ struct Loaded {
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
 };
-static Loaded g_loaded[64][2][3];
+static Loaded g_loaded[64][3][3];
 static std::mutex g_mu;
 
-static int kernel_for(int vpl, bool wta, hipFunction_t *fn)
+static int kernel_for(int vpl, int which, hipFunction_t *fn)
 {
     int dev = 0;
     MCCNN_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, MCCNN_E_UNSUPPORTED,
                   "mccnn_cbca_iter_prog_pair: no current device");
     std::lock_guard<std::mutex> lock(g_mu);
-    Loaded &l = g_loaded[dev][wta ? 1 : 0][vpl - 2];
+    Loaded &l = g_loaded[dev][which][vpl - 2];
     if (!l.fn) {
-        hipError_t e = hipModuleLoadData(&l.mod, kCode[wta ? 1 : 0][vpl - 2]);
+        hipError_t e = hipModuleLoadData(&l.mod, kCode[which][vpl - 2]);
         MCCNN_REQUIRE(e == hipSuccess, (int)e, "mccnn_cbca_iter_prog_pair: hipModuleLoadData: %s", hipGetErrorString(e));
-        e = hipModuleGetFunction(&l.fn, l.mod, kName[wta ? 1 : 0][vpl - 2]);
+        e = hipModuleGetFunction(&l.fn, l.mod, kName[which][vpl - 2]);
         MCCNN_REQUIRE(e == hipSuccess, (int)e, "mccnn_cbca_iter_prog_pair: hipModuleGetFunction(%s): %s",
-                      kName[wta ? 1 : 0][vpl - 2], hipGetErrorString(e));
+                      kName[which][vpl - 2], hipGetErrorString(e));
     }
     *fn = l.fn;
     return 0;
@@ -99,12 +111,15 @@ struct StageEmitter {
 __global__ __launch_bounds__(64) void cbca_prog_build_kernel(const Layout Larg, const uint32_t *__restrict__ sup0,
                                                              const uint32_t *__restrict__ sup1, uint32_t *__restrict__ prog0,
                                                              uint32_t *__restrict__ prog1, int H, int W, int ngroups,
-                                                             int stride)
+                                                             int stride, size_t set_dwords)
 {
     // the handler offsets are looked up with per-lane indices: from LDS (a copy of the kernel argument), not from the
     // kernarg segment in memory (a dependent ~0.4 us load per op)
     __shared__ Layout L;
-    const int lane = threadIdx.x, cg = blockIdx.x, rg = blockIdx.y, job = blockIdx.z;
+    // blockIdx.z = image + 2 * set: set 0 = the full programs, set 1 (set_dwords further on) = the programs without
+    // the anchors whose support region is the pixel itself (cbca_prog_build.h, unit_region)
+    const int lane = threadIdx.x, cg = blockIdx.x, rg = blockIdx.y, job = blockIdx.z & 1;
+    const bool skip_unit = blockIdx.z >= 2;
     {
         const int *src = reinterpret_cast<const int *>(&Larg);
         int *dst = reinterpret_cast<int *>(&L);
@@ -114,7 +129,7 @@ __global__ __launch_bounds__(64) void cbca_prog_build_kernel(const Layout Larg, 
     const int y0 = rg * L.K;
     if (y0 >= H) return;
     const uint32_t *sup = job ? sup1 : sup0;
-    uint32_t *out = (job ? prog1 : prog0) + ((size_t)rg * ngroups + cg) * stride;
+    uint32_t *out = (job ? prog1 : prog0) + (skip_unit ? set_dwords : 0) + ((size_t)rg * ngroups + cg) * stride;
     // the patch's anchors (the same for every lane) and the lanes' work arrays live in LDS, not in scratch memory
     __shared__ Patch P;
     __shared__ int tmp[5 * MAXG][64];
@@ -128,11 +143,15 @@ __global__ __launch_bounds__(64) void cbca_prog_build_kernel(const Layout Larg, 
             ok = x < W && y < H;
             if (ok) {
                 const uint32_t a = sup[(size_t)y * W + x];
-                const int u = (int)(a & 31u), d = (int)((a >> 5) & 31u);
-                up = u < y ? u : y;
-                dn = d < H - 1 - y ? d : H - 1 - y;
-                lowest = y - up;
-                highest = dn > 0 ? y + dn : y0;
+                if (skip_unit && unit_region(a)) {
+                    ok = false;
+                } else {
+                    const int u = (int)(a & 31u), d = (int)((a >> 5) & 31u);
+                    up = u < y ? u : y;
+                    dn = d < H - 1 - y ? d : H - 1 - y;
+                    lowest = y - up;
+                    highest = dn > 0 ? y + dn : y0;
+                }
             }
         }
 #pragma unroll
@@ -235,6 +254,8 @@ static int shape_of(int D, int H, int W, Shape *s, const char *who)
     return 0;
 }
 
+static size_t set_bytes(const Shape &s) { return (size_t)8 * s.band_groups * s.ngroups * s.stride * 4; }
+
 }  // namespace prog
 }  // namespace mccnn
 
@@ -243,7 +264,7 @@ extern "C" size_t mccnn_cbca_prog_bytes(int D, int H, int W)
     using namespace mccnn;
     prog::Shape s;
     if (prog::shape_of(D, H, W, &s, "mccnn_cbca_prog_bytes")) return 0;
-    return (size_t)8 * s.band_groups * s.ngroups * s.stride * 4;
+    return 2 * prog::set_bytes(s);      // the full programs, then the skip programs
 }
 
 extern "C" int mccnn_cbca_prog_build_pair(const mccnn_support_t *support_left, const mccnn_support_t *support_right,
@@ -262,11 +283,11 @@ extern "C" int mccnn_cbca_prog_build_pair(const mccnn_support_t *support_left, c
     rc = check_support_record(support_right, H, W, L, "mccnn_cbca_prog_build_pair", true);
     if (rc) return rc;
     MCCNN_REQUIRE(8 * s.band_groups <= 65535, MCCNN_E_UNSUPPORTED, "mccnn_cbca_prog_build_pair: %d rows exceed the grid", H);
-    const dim3 grid(s.ngroups, 8 * s.band_groups, 2);
+    const dim3 grid(s.ngroups, 8 * s.band_groups, 4);
     hipLaunchKernelGGL(prog::cbca_prog_build_kernel, grid, dim3(64), 0, (hipStream_t)stream, prog::kLayouts[s.vpl - 2],
                        reinterpret_cast<const uint32_t *>(support_left), reinterpret_cast<const uint32_t *>(support_right),
                        reinterpret_cast<uint32_t *>(prog_left), reinterpret_cast<uint32_t *>(prog_right), H, W, s.ngroups,
-                       s.stride);
+                       s.stride, prog::set_bytes(s) / 4);
     rc = check_launch("mccnn_cbca_prog_build_pair");
     if (rc == 0) {
         std::lock_guard<std::mutex> lock(prog::g_built_mu);
@@ -279,7 +300,7 @@ extern "C" int mccnn_cbca_prog_build_pair(const mccnn_support_t *support_left, c
 static int prog_iter(const char *who, const float *in_left, float *out_left, const mccnn_support_t *support_left,
                      const void *prog_left, const float *in_right, float *out_right, const mccnn_support_t *support_right,
                      const void *prog_right, int D, int H, int W, int L, float *disp_left, float *disp_right,
-                     int store_right, bool wta, mccnn_stream_t stream)
+                     int store_right, bool wta, bool skip_unit, mccnn_stream_t stream)
 {
     using namespace mccnn;
     MCCNN_REQUIRE(in_left && out_left && support_left && prog_left && in_right && support_right && prog_right,
@@ -305,8 +326,12 @@ static int prog_iter(const char *who, const float *in_left, float *out_left, con
     rc = prog::check_built(prog_right, support_right, D, H, W);
     if (rc) return rc;
     hipFunction_t fn;
-    rc = prog::kernel_for(s.vpl, wta, &fn);
+    rc = prog::kernel_for(s.vpl, wta ? prog::kWta : skip_unit ? prog::kSkip : prog::kPlain, &fn);
     if (rc) return rc;
+    if (skip_unit) {      // the second program set of both buffers
+        prog_left = static_cast<const char *>(prog_left) + prog::set_bytes(s);
+        prog_right = static_cast<const char *>(prog_right) + prog::set_bytes(s);
+    }
     struct {
         const void *in0, *in1;
         void *out0, *out1;
@@ -332,7 +357,16 @@ extern "C" int mccnn_cbca_iter_prog_pair(const float *in_left, float *out_left, 
                                          int L, mccnn_stream_t stream)
 {
     return prog_iter("mccnn_cbca_iter_prog_pair", in_left, out_left, support_left, prog_left, in_right, out_right,
-                     support_right, prog_right, D, H, W, L, nullptr, nullptr, 1, false, stream);
+                     support_right, prog_right, D, H, W, L, nullptr, nullptr, 1, false, false, stream);
+}
+
+extern "C" int mccnn_cbca_iter_prog_pair_skip(const float *in_left, float *out_left, const mccnn_support_t *support_left,
+                                              const void *prog_left, const float *in_right, float *out_right,
+                                              const mccnn_support_t *support_right, const void *prog_right, int D, int H,
+                                              int W, int L, mccnn_stream_t stream)
+{
+    return prog_iter("mccnn_cbca_iter_prog_pair_skip", in_left, out_left, support_left, prog_left, in_right, out_right,
+                     support_right, prog_right, D, H, W, L, nullptr, nullptr, 1, false, true, stream);
 }
 
 extern "C" int mccnn_cbca_iter_prog_pair_wta(const float *in_left, float *out_left, const mccnn_support_t *support_left,
@@ -342,5 +376,5 @@ extern "C" int mccnn_cbca_iter_prog_pair_wta(const float *in_left, float *out_le
                                              mccnn_stream_t stream)
 {
     return prog_iter("mccnn_cbca_iter_prog_pair_wta", in_left, out_left, support_left, prog_left, in_right, out_right,
-                     support_right, prog_right, D, H, W, L, disparity_left, disparity_right, store_right, true, stream);
+                     support_right, prog_right, D, H, W, L, disparity_left, disparity_right, store_right, true, false, stream);
 }

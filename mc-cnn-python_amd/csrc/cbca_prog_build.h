@@ -95,7 +95,13 @@ MCCNN_PROG_HD uint64_t sched_of(bool ok, int K, int k, int up, int dn, int nd)
 }
 
 // sup0: plane 0 of the support buffer ([H][W] words: bits 0-4 up, 5-9 down, 10-14 left, 15-19 right).
-MCCNN_PROG_HD void patch_setup(const Layout &L, const uint32_t *sup0, int H, int W, int y0, int x0, Patch &P)
+// skip_unit: anchors whose support region is the pixel itself (all four arms 0) take no part.  (0 + x) / 1 = x (pf:156-
+// 161 with aver_num = 1), so from the third consecutive iteration of a ping-pong pair on both buffers already hold such
+// a pixel's value: the "skip" programs neither read it for its own sake nor does the skip kernel write it.
+MCCNN_PROG_HD bool unit_region(uint32_t word) { return (word & 0xfffffu) == 0u; }
+
+MCCNN_PROG_HD void patch_setup(const Layout &L, const uint32_t *sup0, int H, int W, int y0, int x0, Patch &P,
+                               bool skip_unit = false)
 {
     const int K = L.K, G = L.G;
     int up[MAXK][MAXG], dn[MAXK][MAXG];
@@ -109,6 +115,10 @@ MCCNN_PROG_HD void patch_setup(const Layout &L, const uint32_t *sup0, int H, int
             up[k][j] = dn[k][j] = 0;
             if (!ok[k][j]) continue;
             const uint32_t a = sup0[(size_t)y * W + x];
+            if (skip_unit && unit_region(a)) {
+                ok[k][j] = false;
+                continue;
+            }
             const int u = (int)(a & 31u), d = (int)((a >> 5) & 31u);
             up[k][j] = u < y ? u : y;
             dn[k][j] = d < H - 1 - y ? d : H - 1 - y;
@@ -271,10 +281,11 @@ MCCNN_PROG_HD void emit_row(const Layout &L, const Patch &P, const uint32_t *sup
 
 // The whole program of a patch, sequentially (host tests; the device kernel deals the rows to lanes, cbca_prog.hip).
 // Returns the number of dwords the program has (> cap: it did not fit, which the stride bound excludes).
-MCCNN_PROG_HD int build_patch(const Layout &L, const uint32_t *sup0, int H, int W, int y0, int x0, uint32_t *out, int cap)
+MCCNN_PROG_HD int build_patch(const Layout &L, const uint32_t *sup0, int H, int W, int y0, int x0, uint32_t *out, int cap,
+                              bool skip_unit = false)
 {
     Patch P;
-    patch_setup(L, sup0, H, W, y0, x0, P);
+    patch_setup(L, sup0, H, W, y0, x0, P, skip_unit);
     WriteEmitter e = {out, 0, cap, (uint32_t)L.refill | ((uint32_t)L.M0 << 16)};
     int buf[5][MAXG];
     const RowTmp T = {{buf[0], 1}, {buf[1], 1}, {buf[2], 1}, {buf[3], 1}, {buf[4], 1}};

@@ -346,10 +346,14 @@ def cbca_prog_build_pair(support_l, support_r, D, distance_threshold, progs):
 
 
 def cbca_prog_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, progs, D, iterations, distance_threshold, timer=None,
-                   wta_out=None, store_right=True):
+                   wta_out=None, store_right=True, skip_unit_regions=True):
     """cbca_hwd_pair's result (bit for bit) through the program-driven assembly kernel (mccnn_cbca_iter_prog_pair);
     `progs` from cbca_prog_build_pair on the same support buffers and D.  Same ping-pong contract; wta_out /
-    store_right as in cbca_hwd_pair (mccnn_cbca_iter_prog_pair_wta for the last iteration)."""
+    store_right as in cbca_hwd_pair (mccnn_cbca_iter_prog_pair_wta for the last iteration).
+
+    skip_unit_regions: from the third iteration on, pixels whose support region is the pixel itself are left alone
+    (mccnn_cbca_iter_prog_pair_skip): (0 + x) / 1 = x, and after iterations 1 and 2 both ping-pong buffers hold that
+    value - the same bits everywhere, fewer bytes moved.  The iteration that carries the WTA runs the full programs."""
     H, W, Dp = vol_l.shape
     assert Dp == hwd_pitch(D)
     for t in (tmp_l, vol_r, tmp_r):
@@ -364,8 +368,9 @@ def cbca_prog_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, progs, D, i
     if wta_out is not None and (n < 1 or D > cbca_hwd_wta_max_d()):
         raise ValueError("cbca_prog_pair: the fused WTA needs at least one iteration and D <= %d" % cbca_hwd_wta_max_d())
     for it in range(n):
-        timer.start("cbca_iter_prog_pair")
-        if wta_out is not None and it == n - 1:
+        fused = wta_out is not None and it == n - 1
+        timer.start("cbca_iter_prog_pair_skip" if skip_unit_regions and it >= 2 and not fused else "cbca_iter_prog_pair")
+        if fused:
             for t in wta_out:
                 if tuple(t.shape) != (H, W) or t.dtype != torch.float32 or not t.is_contiguous():
                     raise ValueError("cbca_prog_pair: wta_out must be two contiguous float32 [H,W] tensors")
@@ -375,10 +380,10 @@ def cbca_prog_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, progs, D, i
                                                         hip.ptr(wta_out[1]), 1 if store_right else 0, hip.stream()),
                       "mccnn_cbca_iter_prog_pair_wta")
         else:
-            hip.check(lib.mccnn_cbca_iter_prog_pair(hip.ptr(sl), hip.ptr(dl), hip.ptr(support_l), hip.ptr(progs[0]),
-                                                    hip.ptr(sr), hip.ptr(dr), hip.ptr(support_r), hip.ptr(progs[1]), int(D),
-                                                    H, W, int(distance_threshold), hip.stream()),
-                      "mccnn_cbca_iter_prog_pair")
+            fn, who = ((lib.mccnn_cbca_iter_prog_pair_skip, "mccnn_cbca_iter_prog_pair_skip")
+                       if skip_unit_regions and it >= 2 else (lib.mccnn_cbca_iter_prog_pair, "mccnn_cbca_iter_prog_pair"))
+            hip.check(fn(hip.ptr(sl), hip.ptr(dl), hip.ptr(support_l), hip.ptr(progs[0]), hip.ptr(sr), hip.ptr(dr),
+                         hip.ptr(support_r), hip.ptr(progs[1]), int(D), H, W, int(distance_threshold), hip.stream()), who)
         timer.stop()
         sl, dl, sr, dr = dl, sl, dr, sr
     return (sl, dl), (sr, dr)

@@ -44,10 +44,17 @@ def prog_stride_dwords(L):
     return -(-n // 64) * 64
 
 
-def plan_units(sup0, H, W, y0, x0, L):
+def unit_region(word):
+    """True for a pixel whose support region is the pixel itself (all four arms 0): (0 + x) / 1 = x, so from the third
+    consecutive iteration of a ping-pong pair on both buffers already hold its value (pf:149-163 with aver_num = 1)."""
+    return (int(word) & 0xfffff) == 0
+
+
+def plan_units(sup0, H, W, y0, x0, L, skip_unit=False):
     """The patch's work as a list of window units in execution order: (lo, hi, p_last, runs) - load virtual slots
     lo .. hi of one region row (p_last = pixel index of slot hi relative to the patch's first region row), then the arm
-    runs (dir, column j, anchor set, first slot, n) that read them."""
+    runs (dir, column j, anchor set, first slot, n) that read them.  skip_unit: anchors whose region is the pixel itself
+    take no part (the kernel's skip variant neither divides nor stores them)."""
     K, G, WW = L["K"], L["G"], L["W"]
     MAXD, MAXA = L["MAXD"], L["MAXA"]
     units = []
@@ -57,7 +64,7 @@ def plan_units(sup0, H, W, y0, x0, L):
         y = y0 + k
         for j in range(G):
             x = x0 + j
-            if x < W and y < H:
+            if x < W and y < H and not (skip_unit and unit_region(sup0[y, x])):
                 u, d, _, _ = arms_of(sup0[y, x])
                 u, d = min(u, y), min(d, H - 1 - y)
                 up[k, j], dn[k, j], ok[k, j] = u, d, True
@@ -152,7 +159,7 @@ def plan_units(sup0, H, W, y0, x0, L):
     return units
 
 
-def build_program(sup0, H, W, y0, x0, L):
+def build_program(sup0, H, W, y0, x0, L, skip_unit=False):
     """sup0: [H, W] uint32 support words (plane 0).  Returns the uint32 ops of the patch at rows y0.., columns x0...
     One window (NB = 1): LOAD (which waits), the unit's arms, next unit.  Two windows: the next unit's LOAD is issued
     before the current unit's arms, WAIT k (k = slots of that newest LOAD) lets exactly the current window arrive."""
@@ -166,7 +173,7 @@ def build_program(sup0, H, W, y0, x0, L):
             ops.append(L["refill"] | (M0 << 16))
         ops.append(op & 0xffffffff)
 
-    units = plan_units(sup0, H, W, y0, x0, L)
+    units = plan_units(sup0, H, W, y0, x0, L, skip_unit)
 
     def load(i):
         lo, hi, p, _ = units[i]
@@ -204,7 +211,7 @@ def build_program(sup0, H, W, y0, x0, L):
     return np.array(ops, np.uint32)
 
 
-def build_all(sup0, H, W, L):
+def build_all(sup0, H, W, L, skip_unit=False):
     """[row groups of the 8 bands][column groups][stride] uint32, the layout the kernel indexes."""
     K, G = L["K"], L["G"]
     br = band_rows_of(H, K)
@@ -218,7 +225,7 @@ def build_all(sup0, H, W, L):
         if y0 >= H:
             continue
         for cg in range(ngroups):
-            p = build_program(sup0, H, W, y0, cg * G, L)
+            p = build_program(sup0, H, W, y0, cg * G, L, skip_unit)
             assert len(p) <= stride, (len(p), stride)
             longest = max(longest, len(p))
             out[rg, cg, :len(p)] = p

@@ -10,5 +10,9 @@ extern "C" int prog_build_patch(const uint32_t *sup0, int H, int W, int y0, int 
 {
     return mccnn::prog::build_patch(kL, sup0, H, W, y0, x0, out, cap);
 }
+extern "C" int prog_build_patch_skip(const uint32_t *sup0, int H, int W, int y0, int x0, uint32_t *out, int cap)
+{
+    return mccnn::prog::build_patch(kL, sup0, H, W, y0, x0, out, cap, true);
+}
 extern "C" int prog_stride_dwords(void) { return mccnn::prog::stride_dwords(kL.K, kL.G, kL.W); }
 extern "C" int prog_band_rows(int H) { return mccnn::prog::band_rows_of(H, kL.K); }

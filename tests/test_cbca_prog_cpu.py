@@ -111,26 +111,32 @@ def test_cxx_builder_equals_the_python_statement(tmp_path, vpl, k, w):
         assert lib.prog_band_rows(H) == ref.band_rows_of(H, k)
         for y0 in range(0, H, k):
             for x0 in range(0, W, L["G"]):
-                want = ref.build_program(sup0, H, W, y0, x0, L)
-                got = np.zeros(cap, np.uint32)
-                n = lib.prog_build_patch(padded.ctypes.data_as(u32p), H, W, y0, x0, got.ctypes.data_as(u32p), cap)
-                assert n == len(want) <= cap, (H, W, y0, x0, n, len(want))
-                assert np.array_equal(got[:n], want), (H, W, y0, x0)
+                # the full programs and the ones that leave out the anchors whose region is the pixel itself
+                for skip, fn in ((False, lib.prog_build_patch), (True, lib.prog_build_patch_skip)):
+                    want = ref.build_program(sup0, H, W, y0, x0, L, skip_unit=skip)
+                    got = np.zeros(cap, np.uint32)
+                    n = fn(padded.ctypes.data_as(u32p), H, W, y0, x0, got.ctypes.data_as(u32p), cap)
+                    assert n == len(want) <= cap, (H, W, y0, x0, skip, n, len(want))
+                    assert np.array_equal(got[:n], want), (H, W, y0, x0, skip)
 
 
-def simulate(g, L, img, vol, code_addr=0x7e00fffff000):
-    """Runs every workgroup of one single-volume launch of the generated kernel in the simulator."""
+def simulate(g, L, img, vol, code_addr=0x7e00fffff000, out_init=None):
+    """Runs every workgroup of one single-volume launch of the generated kernel in the simulator.  The skip kernel
+    (g.P.skip) runs the skip programs; out_init [D, H, W] is then what the output buffer holds beforehand."""
     P = g.P
     D, H, W = vol.shape
     VPL = P.VPL
     Dp = -(-D // 4) * 4 if VPL != 3 else -(-D // 3) * 3
     sup0 = support_words(img)
-    progs, meta = ref.build_all(sup0, H, W, L)
+    progs, meta = ref.build_all(sup0, H, W, L, skip_unit=P.skip)
     hwd = np.zeros((H, W, Dp), np.float32)
     hwd[:, :, :D] = vol.transpose(1, 2, 0)
     mem = asm_sim.Memory()
     a_in = mem.alloc(hwd)
-    a_out = mem.alloc(np.full((H, W, Dp), np.nan, np.float32))
+    out0 = np.full((H, W, Dp), np.nan, np.float32)
+    if out_init is not None:
+        out0[:, :, :D] = out_init.transpose(1, 2, 0)
+    a_out = mem.alloc(out0)
     a_prog = mem.alloc(progs)
     a_sup = mem.alloc(np.concatenate([sup0.reshape(-1), np.zeros(64, np.uint32)]))
     nchunks = -(-Dp // (64 * VPL))
@@ -168,6 +174,46 @@ def test_generated_kernel_reproduces_the_oracle_in_the_simulator(vpl, w, nb, H, 
     got, st = simulate(g, L, img, vol)
     want = oracle_cbca(img, vol)
     assert np.array_equal(got, want, equal_nan=True), "max diff %g" % np.nanmax(np.abs(got - want))
+
+
+@pytest.mark.parametrize("vpl,w,k,H,W,D,seed,flat", [(4, 20, 4, 12, 17, 8, 0, False), (4, 12, 2, 14, 23, 5, 1, False),
+                                                     (3, 12, 4, 14, 23, 6, 4, False), (2, 12, 4, 11, 16, 6, 5, False),
+                                                     (4, 20, 4, 9, 33, 4, 2, True), (4, 20, 4, 24, 32, 8, 3, False)])
+def test_skip_kernel_leaves_unit_regions_alone_and_equals_the_oracle_in_the_simulator(vpl, w, k, H, W, D, seed, flat):
+    """The skip programs + the skip kernel (third and later iterations of a ping-pong pair): pixels whose support region
+    is the pixel itself are neither read for their own sake nor written - the output buffer must already hold their
+    value (here: the oracle's second iteration) - and every other pixel gets the oracle's bits.  Unit-region pixels that
+    were NOT pre-filled stay NaN: the kernel really does not touch them."""
+    g = gen.Gen(gen.Params(vpl=vpl, K=k, W=w, skip=True)).build()
+    L = g.layout()
+    img, vol0 = make_case(H, W, D, seed, flat)
+    v1 = oracle_cbca(img, vol0)
+    v2 = oracle_cbca(img, v1)
+    v3 = oracle_cbca(img, v2)
+    unit = (support_words(img) & 0xfffff) == 0
+    assert flat or unit.any()
+    assert np.array_equal(v3[:, unit], v2[:, unit]) and np.array_equal(v2[:, unit], v1[:, unit])     # the fixed point
+    got, _ = simulate(g, L, img, v2, out_init=v1)          # iteration 3 writes into the buffer iteration 1 wrote
+    assert np.array_equal(got, v3, equal_nan=True)
+    untouched, _ = simulate(g, L, img, v2)                 # nothing pre-filled: unit regions stay NaN
+    assert np.isnan(untouched[:, unit]).all() and np.array_equal(untouched[:, ~unit], v3[:, ~unit])
+
+
+def test_unit_regions_are_fixed_points_after_one_iteration_including_negative_zero():
+    """What the skip variant rests on (pf:156-161 with aver_num = 1): v1 = (0 + v0) / 1 turns -0.0 into +0.0 and is
+    otherwise v0; v2 = v1 bit for bit, also for inf, NaN and subnormals."""
+    img, vol = make_case(24, 32, 8, 3)
+    unit = (support_words(img) & 0xfffff) == 0
+    assert unit.any()
+    vol[:, unit] = np.resize(np.array([-0.0, 0.0, np.inf, -np.inf, np.nan, 1e-42, -1e-42, 1.5], np.float32),
+                             vol[:, unit].shape)
+    v1 = oracle_cbca(img, vol)
+    v2 = oracle_cbca(img, v1)
+    a, b = v1[:, unit].view(np.uint32), v2[:, unit].view(np.uint32)
+    nan = np.isnan(v1[:, unit])
+    assert np.array_equal(a[~nan], b[~nan]) and np.isnan(v2[:, unit][nan]).all()
+    assert not np.signbit(v1[:, unit][vol[:, unit] == 0]).any()          # -0.0 became +0.0 in the first iteration
+    assert np.array_equal(v1[:, unit][~nan & (vol[:, unit] != 0)], vol[:, unit][~nan & (vol[:, unit] != 0)])
 
 
 def test_generated_kernel_with_scalar_prefetch_in_the_simulator():

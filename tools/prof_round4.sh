@@ -8,6 +8,7 @@ if [ "$PART" = 1 ]; then
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r04f -o bench -- python $R/bench.py --fast --steps 20 --warmup 2 --no-cpu-baseline --no-parity > $O/prof_r04f_bench.json 2> $O/prof_r04f.err
   cd $R
   SETS="1 2 3 4 5 6" timeout 400 bash tools/pmc_kernel.sh cbca_iter_prog_pair mccnn_cbca_prog_v4 > $O/r4_pmc_cbca_prog.txt 2>&1
+  SETS="1 3 4 5" timeout 300 bash tools/pmc_kernel.sh cbca_iter_prog_pair_skip mccnn_cbca_prog_v4_skip > $O/r4_pmc_cbca_prog_skip.txt 2>&1
   SETS="4 5" timeout 200 bash tools/pmc_kernel.sh cbca_iter_hwd_pair cbca_hwd_kernel > $O/r4_pmc_cbca_hwd.txt 2>&1
   SETS="4 5" timeout 200 bash tools/pmc_kernel.sh cbca_iter_pair cbca_stream_kernel > $O/r4_pmc_cbca_stream.txt 2>&1
   SETS="2 3 4 5 6" timeout 300 bash tools/pmc_kernel.sh sgm_pass_h sgm_pass_kernel > $O/r4_pmc_sgm_pass.txt 2>&1
