@@ -172,8 +172,8 @@ int mccnn_cbca_iter_hwd_pair_wta(const float *in_left, float *out_left, const mc
  * compiled once per image into a linear program per patch (mccnn_cbca_prog_build_pair, after mccnn_cross_arms), and the
  * iteration is an interpreter of those programs written in gfx950 assembly (csrc/asm/cbca_prog_gen.py).  The programs
  * depend on the image, on D (disparities per lane) and on nothing else: one build serves all 18 iterations of a pair.
- *   mccnn_cbca_prog_bytes: size of ONE image's program buffer (two program sets: the full programs and the ones
- *     mccnn_cbca_iter_prog_pair_skip runs); 0 when the shape is outside what the programs encode
+ *   mccnn_cbca_prog_bytes: size of ONE image's program buffer (room for two program sets: the full programs and the
+ *     ones mccnn_cbca_iter_prog_pair_skip runs); 0 when the shape is outside what the programs encode
  *     (W > 2180 columns, or volumes beyond a buffer descriptor's reach) - callers then stay with mccnn_cbca_iter_hwd_pair.
  *   support_*: the whole buffers mccnn_cross_arms wrote (plane 0 is read).  L <= 14; outputs must not alias inputs.
  *   mccnn_cbca_iter_prog_pair refuses (MCCNN_E_INVALID) program buffers mccnn_cbca_prog_build_pair has not written, built
@@ -198,11 +198,14 @@ int mccnn_cbca_iter_prog_pair_wta(const float *in_left, float *out_left, const m
  * whose support region is the pixel itself (all four arms 0: count 1) gets (0 + x) / 1 = x (pf:156-161), so after two
  * consecutive iterations in -> out, out -> in both buffers hold its final value (the first iteration turns a -0.0 into
  * +0.0, the second copies that back).  From the THIRD consecutive iteration on this entry point may replace
- * mccnn_cbca_iter_prog_pair: it runs the second program set mccnn_cbca_prog_build_pair writes (such anchors take no
+ * mccnn_cbca_iter_prog_pair: it runs the second program set, which mccnn_cbca_prog_build_skip_pair writes into the same
+ * buffers (a launch of its own, so that it can run beside the first iterations; such anchors take no
  * part: not loaded for their own sake, not divided, NOT STORED) - same bits in every pixel of out_*, fewer bytes moved
  * (on the synthetic benchmark pair 46 % of the pixels: 27 % less HBM traffic per iteration).  The caller's promise:
  * out_* already holds, for every such pixel, what in_* holds.  match.py's 16-iteration aggregation (pf:117-183 called
  * with max_average_time = 16) runs iterations 3 .. 15 this way; the last one carries the WTA and needs every pixel. */
+int mccnn_cbca_prog_build_skip_pair(const mccnn_support_t *support_left, const mccnn_support_t *support_right, int D,
+                                    int H, int W, int L, void *prog_left, void *prog_right, mccnn_stream_t stream);
 int mccnn_cbca_iter_prog_pair_skip(const float *in_left, float *out_left, const mccnn_support_t *support_left,
                                    const void *prog_left, const float *in_right, float *out_right,
                                    const mccnn_support_t *support_right, const void *prog_right, int D, int H, int W,

@@ -111,15 +111,15 @@ struct StageEmitter {
 __global__ __launch_bounds__(64) void cbca_prog_build_kernel(const Layout Larg, const uint32_t *__restrict__ sup0,
                                                              const uint32_t *__restrict__ sup1, uint32_t *__restrict__ prog0,
                                                              uint32_t *__restrict__ prog1, int H, int W, int ngroups,
-                                                             int stride, size_t set_dwords)
+                                                             int stride, size_t set_dwords, int skip_set)
 {
     // the handler offsets are looked up with per-lane indices: from LDS (a copy of the kernel argument), not from the
     // kernarg segment in memory (a dependent ~0.4 us load per op)
     __shared__ Layout L;
-    // blockIdx.z = image + 2 * set: set 0 = the full programs, set 1 (set_dwords further on) = the programs without
-    // the anchors whose support region is the pixel itself (cbca_prog_build.h, unit_region)
-    const int lane = threadIdx.x, cg = blockIdx.x, rg = blockIdx.y, job = blockIdx.z & 1;
-    const bool skip_unit = blockIdx.z >= 2;
+    // blockIdx.z = image; skip_set 0 = the full programs, 1 = the second set (set_dwords further on): the programs
+    // without the anchors whose support region is the pixel itself (cbca_prog_build.h, unit_region)
+    const int lane = threadIdx.x, cg = blockIdx.x, rg = blockIdx.y, job = blockIdx.z;
+    const bool skip_unit = skip_set != 0;
     {
         const int *src = reinterpret_cast<const int *>(&Larg);
         int *dst = reinterpret_cast<int *>(&L);
@@ -206,15 +206,16 @@ struct Built {
     const void *support;
     unsigned long long gen;
 };
-static std::unordered_map<const void *, Built> g_built;
+static std::unordered_map<const void *, Built> g_built[2];      // [0] the full programs, [1] the skip programs
 static std::mutex g_built_mu;
 
-static int check_built(const void *prog, const mccnn_support_t *support, int D, int H, int W)
+static int check_built(const void *prog, const mccnn_support_t *support, int D, int H, int W, int set)
 {
     std::lock_guard<std::mutex> lock(g_built_mu);
-    const auto it = g_built.find(prog);
-    MCCNN_REQUIRE(it != g_built.end(), MCCNN_E_INVALID,
-                  "mccnn_cbca_iter_prog_pair: this program buffer has not been written by mccnn_cbca_prog_build_pair");
+    const auto it = g_built[set].find(prog);
+    MCCNN_REQUIRE(it != g_built[set].end(), MCCNN_E_INVALID,
+                  "mccnn_cbca_iter_prog_pair: this program buffer has not been written by mccnn_cbca_prog_build_%spair",
+                  set ? "skip_" : "");
     const Built &b = it->second;
     MCCNN_REQUIRE(b.D == D && b.H == H && b.W == W, MCCNN_E_INVALID,
                   "mccnn_cbca_iter_prog_pair: programs were built for %dx%dx%d, called with %dx%dx%d", b.W, b.H, b.D, W, H, D);
@@ -267,34 +268,47 @@ extern "C" size_t mccnn_cbca_prog_bytes(int D, int H, int W)
     return 2 * prog::set_bytes(s);      // the full programs, then the skip programs
 }
 
+static int prog_build(const char *who, int set, const mccnn_support_t *support_left, const mccnn_support_t *support_right,
+                      int D, int H, int W, int L, void *prog_left, void *prog_right, mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(support_left && support_right && prog_left && prog_right, MCCNN_E_INVALID, "%s: null pointer", who);
+    MCCNN_REQUIRE(L >= 1 && L <= 14, MCCNN_E_UNSUPPORTED, "%s: L=%d outside [1,14]", who, L);
+    prog::Shape s;
+    int rc = prog::shape_of(D, H, W, &s, who);
+    if (rc) return rc;
+    rc = check_support_record(support_left, H, W, L, who, true);
+    if (rc) return rc;
+    rc = check_support_record(support_right, H, W, L, who, true);
+    if (rc) return rc;
+    MCCNN_REQUIRE(8 * s.band_groups <= 65535, MCCNN_E_UNSUPPORTED, "%s: %d rows exceed the grid", who, H);
+    const dim3 grid(s.ngroups, 8 * s.band_groups, 2);
+    hipLaunchKernelGGL(prog::cbca_prog_build_kernel, grid, dim3(64), 0, (hipStream_t)stream, prog::kLayouts[s.vpl - 2],
+                       reinterpret_cast<const uint32_t *>(support_left), reinterpret_cast<const uint32_t *>(support_right),
+                       reinterpret_cast<uint32_t *>(prog_left), reinterpret_cast<uint32_t *>(prog_right), H, W, s.ngroups,
+                       s.stride, prog::set_bytes(s) / 4, set);
+    rc = check_launch(who);
+    if (rc == 0) {
+        std::lock_guard<std::mutex> lock(prog::g_built_mu);
+        prog::g_built[set][prog_left] = prog::Built{D, H, W, support_left, support_generation(support_left)};
+        prog::g_built[set][prog_right] = prog::Built{D, H, W, support_right, support_generation(support_right)};
+    }
+    return rc;
+}
+
 extern "C" int mccnn_cbca_prog_build_pair(const mccnn_support_t *support_left, const mccnn_support_t *support_right,
                                           int D, int H, int W, int L, void *prog_left, void *prog_right,
                                           mccnn_stream_t stream)
 {
-    using namespace mccnn;
-    MCCNN_REQUIRE(support_left && support_right && prog_left && prog_right, MCCNN_E_INVALID,
-                  "mccnn_cbca_prog_build_pair: null pointer");
-    MCCNN_REQUIRE(L >= 1 && L <= 14, MCCNN_E_UNSUPPORTED, "mccnn_cbca_prog_build_pair: L=%d outside [1,14]", L);
-    prog::Shape s;
-    int rc = prog::shape_of(D, H, W, &s, "mccnn_cbca_prog_build_pair");
-    if (rc) return rc;
-    rc = check_support_record(support_left, H, W, L, "mccnn_cbca_prog_build_pair", true);
-    if (rc) return rc;
-    rc = check_support_record(support_right, H, W, L, "mccnn_cbca_prog_build_pair", true);
-    if (rc) return rc;
-    MCCNN_REQUIRE(8 * s.band_groups <= 65535, MCCNN_E_UNSUPPORTED, "mccnn_cbca_prog_build_pair: %d rows exceed the grid", H);
-    const dim3 grid(s.ngroups, 8 * s.band_groups, 4);
-    hipLaunchKernelGGL(prog::cbca_prog_build_kernel, grid, dim3(64), 0, (hipStream_t)stream, prog::kLayouts[s.vpl - 2],
-                       reinterpret_cast<const uint32_t *>(support_left), reinterpret_cast<const uint32_t *>(support_right),
-                       reinterpret_cast<uint32_t *>(prog_left), reinterpret_cast<uint32_t *>(prog_right), H, W, s.ngroups,
-                       s.stride, prog::set_bytes(s) / 4);
-    rc = check_launch("mccnn_cbca_prog_build_pair");
-    if (rc == 0) {
-        std::lock_guard<std::mutex> lock(prog::g_built_mu);
-        prog::g_built[prog_left] = prog::Built{D, H, W, support_left, support_generation(support_left)};
-        prog::g_built[prog_right] = prog::Built{D, H, W, support_right, support_generation(support_right)};
-    }
-    return rc;
+    return prog_build("mccnn_cbca_prog_build_pair", 0, support_left, support_right, D, H, W, L, prog_left, prog_right, stream);
+}
+
+extern "C" int mccnn_cbca_prog_build_skip_pair(const mccnn_support_t *support_left, const mccnn_support_t *support_right,
+                                               int D, int H, int W, int L, void *prog_left, void *prog_right,
+                                               mccnn_stream_t stream)
+{
+    return prog_build("mccnn_cbca_prog_build_skip_pair", 1, support_left, support_right, D, H, W, L, prog_left, prog_right,
+                      stream);
 }
 
 static int prog_iter(const char *who, const float *in_left, float *out_left, const mccnn_support_t *support_left,
@@ -321,9 +335,9 @@ static int prog_iter(const char *who, const float *in_left, float *out_left, con
     if (rc) return rc;
     rc = check_support_record(support_right, H, W, L, who, true);
     if (rc) return rc;
-    rc = prog::check_built(prog_left, support_left, D, H, W);
+    rc = prog::check_built(prog_left, support_left, D, H, W, skip_unit ? 1 : 0);
     if (rc) return rc;
-    rc = prog::check_built(prog_right, support_right, D, H, W);
+    rc = prog::check_built(prog_right, support_right, D, H, W, skip_unit ? 1 : 0);
     if (rc) return rc;
     hipFunction_t fn;
     rc = prog::kernel_for(s.vpl, wta ? prog::kWta : skip_unit ? prog::kSkip : prog::kPlain, &fn);

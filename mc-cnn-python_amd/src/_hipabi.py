@@ -47,6 +47,7 @@ SIGNATURES = {
     "mccnn_cbca_prog_bytes": (_sz, [_i, _i, _i]),
     "mccnn_cbca_prog_build_pair": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mccnn_cbca_iter_prog_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mccnn_cbca_prog_build_skip_pair": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mccnn_cbca_iter_prog_pair_skip": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mccnn_cbca_iter_prog_pair_wta": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "mccnn_wta_hwd": (_i, [_vp, _i, _i, _i, _vp, _vp]),

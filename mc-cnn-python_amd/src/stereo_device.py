@@ -333,27 +333,35 @@ def cbca_prog_buffers(D, H, W, device):
     return (torch.empty((n // 4,), dtype=torch.int32, device=device), torch.empty((n // 4,), dtype=torch.int32, device=device))
 
 
-def cbca_prog_build_pair(support_l, support_r, D, distance_threshold, progs):
-    """Compiles both images' support regions into the per-patch programs of the assembly aggregation kernel
-    (mccnn_cbca_prog_build_pair): once per pair, after cross_arms_pair, for all iterations."""
+def cbca_prog_build_pair(support_l, support_r, D, distance_threshold, progs, which="both"):
+    """Compiles both images' support regions into the per-patch programs of the assembly aggregation kernel: once per
+    pair, after cross_arms_pair, for all iterations.  which: "full" (mccnn_cbca_prog_build_pair: what every iteration can
+    run), "skip" (mccnn_cbca_prog_build_skip_pair: the second set in the same buffers, which third and later iterations
+    run, cbca_prog_pair) or "both" - two launches, so a caller may put the second one beside the first iterations."""
     H, W = support_l.shape
     _check_support(support_l, H, W, "cbca_prog_build_pair")
     _check_support(support_r, H, W, "cbca_prog_build_pair")
-    hip.check(hip.load().mccnn_cbca_prog_build_pair(hip.ptr(support_l), hip.ptr(support_r), int(D), H, W,
-                                                    int(distance_threshold), hip.ptr(progs[0]), hip.ptr(progs[1]),
-                                                    hip.stream()), "mccnn_cbca_prog_build_pair")
+    if which not in ("full", "skip", "both"):
+        raise ValueError("cbca_prog_build_pair: which must be 'full', 'skip' or 'both'")
+    lib = hip.load()
+    for name, fn in (("full", lib.mccnn_cbca_prog_build_pair), ("skip", lib.mccnn_cbca_prog_build_skip_pair)):
+        if which in (name, "both"):
+            hip.check(fn(hip.ptr(support_l), hip.ptr(support_r), int(D), H, W, int(distance_threshold), hip.ptr(progs[0]),
+                         hip.ptr(progs[1]), hip.stream()), "mccnn_cbca_prog_build_%spair" % ("skip_" if name == "skip" else ""))
     return progs
 
 
 def cbca_prog_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, progs, D, iterations, distance_threshold, timer=None,
-                   wta_out=None, store_right=True, skip_unit_regions=True):
+                   wta_out=None, store_right=True, skip_unit_regions=True, skip_ready=None):
     """cbca_hwd_pair's result (bit for bit) through the program-driven assembly kernel (mccnn_cbca_iter_prog_pair);
     `progs` from cbca_prog_build_pair on the same support buffers and D.  Same ping-pong contract; wta_out /
     store_right as in cbca_hwd_pair (mccnn_cbca_iter_prog_pair_wta for the last iteration).
 
     skip_unit_regions: from the third iteration on, pixels whose support region is the pixel itself are left alone
     (mccnn_cbca_iter_prog_pair_skip): (0 + x) / 1 = x, and after iterations 1 and 2 both ping-pong buffers hold that
-    value - the same bits everywhere, fewer bytes moved.  The iteration that carries the WTA runs the full programs."""
+    value - the same bits everywhere, fewer bytes moved.  The iteration that carries the WTA runs the full programs.
+    skip_ready: an event after which the second program set is complete when it was built on another stream (the
+    current stream waits for it in front of the first iteration that needs it)."""
     H, W, Dp = vol_l.shape
     assert Dp == hwd_pitch(D)
     for t in (tmp_l, vol_r, tmp_r):
@@ -382,6 +390,8 @@ def cbca_prog_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, progs, D, i
         else:
             fn, who = ((lib.mccnn_cbca_iter_prog_pair_skip, "mccnn_cbca_iter_prog_pair_skip")
                        if skip_unit_regions and it >= 2 else (lib.mccnn_cbca_iter_prog_pair, "mccnn_cbca_iter_prog_pair"))
+            if skip_ready is not None and skip_unit_regions and it == 2:
+                torch.cuda.current_stream().wait_event(skip_ready)
             hip.check(fn(hip.ptr(sl), hip.ptr(dl), hip.ptr(support_l), hip.ptr(progs[0]), hip.ptr(sr), hip.ptr(dr),
                          hip.ptr(support_r), hip.ptr(progs[1]), int(D), H, W, int(distance_threshold), hip.stream()), who)
         timer.stop()
@@ -728,10 +738,18 @@ class StereoMatcher(object):
                 self._side = torch.cuda.Stream()
             main = torch.cuda.current_stream()
             self._side.wait_stream(main)
+            skip_ready = None
             with torch.cuda.stream(self._side):
                 sup_l, sup_r = cross_arms_pair(L, R, hp["cbca_intensity"], hp["cbca_distance"], ws["sup_l"], ws["sup_r"])
                 if ws["progs"] is not None:
-                    cbca_prog_build_pair(sup_l, sup_r, D, hp["cbca_distance"], ws["progs"])
+                    cbca_prog_build_pair(sup_l, sup_r, D, hp["cbca_distance"], ws["progs"], "full")
+                    full_ready = torch.cuda.Event()
+                    full_ready.record(self._side)
+                    # the second program set is first needed by the third iteration of the second aggregation: it is
+                    # built beside the first aggregation and SGM (bandwidth-bound kernels; the builder is latency-bound)
+                    cbca_prog_build_pair(sup_l, sup_r, D, hp["cbca_distance"], ws["progs"], "skip")
+                    skip_ready = torch.cuda.Event()
+                    skip_ready.record(self._side)
 
         timer.start("features")
         if self.features == "split_f16":
@@ -753,7 +771,10 @@ class StereoMatcher(object):
             keep["cv"] = (hwd_to_dhw(lh, D), hwd_to_dhw(rh, D)) if direct else (lcv.clone(), rcv.clone())
 
         if overlap:
-            torch.cuda.current_stream().wait_stream(self._side)
+            if skip_ready is not None:
+                torch.cuda.current_stream().wait_event(full_ready)
+            else:
+                torch.cuda.current_stream().wait_stream(self._side)
         else:
             timer.start("cross_arms")
             sup_l, sup_r = cross_arms_pair(L, R, hp["cbca_intensity"], hp["cbca_distance"], ws["sup_l"], ws["sup_r"])
@@ -777,7 +798,8 @@ class StereoMatcher(object):
                 # the program-driven assembly kernel where its programs exist, cbca_hwd_kernel otherwise (same bits)
                 if progs is None:
                     return cbca_hwd_pair(lh, lt, sup_l, rh, rt, sup_r, D, int(n), hp["cbca_distance"], timer, **kw)
-                return cbca_prog_pair(lh, lt, sup_l, rh, rt, sup_r, progs, D, int(n), hp["cbca_distance"], timer, **kw)
+                return cbca_prog_pair(lh, lt, sup_l, rh, rt, sup_r, progs, D, int(n), hp["cbca_distance"], timer,
+                                      skip_ready=skip_ready if overlap else None, **kw)
 
             (lh, lt), (rh, rt) = aggregate_hwd(lh, as_hwd(b0), rh, as_hwd(b1), hp["cbca_num_iterations1"])
             if keep is not None:
@@ -791,6 +813,8 @@ class StereoMatcher(object):
             fuse = int(hp["cbca_num_iterations2"]) >= 1 and D <= cbca_hwd_wta_max_d()
             (lh, lt), (rh, rt) = aggregate_hwd(lh, lt, rh, rt, hp["cbca_num_iterations2"],
                                                wta_out=(m[0], m[1]) if fuse else None, store_right=keep is not None)
+            if overlap and skip_ready is not None:
+                torch.cuda.current_stream().wait_event(skip_ready)      # joins the side stream whatever the iteration count
             if keep is not None:
                 keep["cbca2"] = (hwd_to_dhw(lh, D), hwd_to_dhw(rh, D))
             if fuse:

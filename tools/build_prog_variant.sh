@@ -11,7 +11,8 @@ A=build/variants/$NAME/asm; mkdir -p $A
 for v in 2 3 4; do
   python3 csrc/asm/cbca_prog_gen.py --vpl $v $GEN -o $A/cbca_prog_v$v.s --header $A/cbca_prog_layout_v$v.h
   python3 csrc/asm/cbca_prog_gen.py --vpl $v $GEN --wta -o $A/cbca_prog_v${v}w.s
-  for s in v$v v${v}w; do
+  python3 csrc/asm/cbca_prog_gen.py --vpl $v $GEN --skip -o $A/cbca_prog_v${v}s.s
+  for s in v$v v${v}w v${v}s; do
     $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c $A/cbca_prog_$s.s -o $A/cbca_prog_$s.o
     $LLVM/ld.lld -shared $A/cbca_prog_$s.o -o $A/cbca_prog_$s.hsaco
     python3 csrc/asm/bin2inc.py $A/cbca_prog_$s.hsaco $A/cbca_prog_$s.inc
