@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64) void cbca_prog_build_kernel(const Layout Larg, 
     uint32_t *out = (job ? prog1 : prog0) + (skip_unit ? set_dwords : 0) + ((size_t)rg * ngroups + cg) * stride;
     // the patch's anchors (the same for every lane) and the lanes' work arrays live in LDS, not in scratch memory
     __shared__ Patch P;
-    __shared__ int tmp[5 * MAXG][64];
+    __shared__ uint8_t tmp[5 * MAXG][64];
     {   // patch_setup (cbca_prog_build.h) with one anchor per lane: 20 independent loads instead of 20 in a row
         const int K = L.K, G = L.G, x0 = cg * L.G;
         const int k = lane / G, j = lane - k * G;
@@ -170,8 +170,8 @@ __global__ __launch_bounds__(64) void cbca_prog_build_kernel(const Layout Larg, 
         }
     }
     __syncthreads();
-    const RowTmp T = {{&tmp[0 * MAXG][lane], 64}, {&tmp[1 * MAXG][lane], 64}, {&tmp[2 * MAXG][lane], 64},
-                      {&tmp[3 * MAXG][lane], 64}, {&tmp[4 * MAXG][lane], 64}};
+    const RowTmpT<uint8_t> T = {{&tmp[0 * MAXG][lane], 64}, {&tmp[1 * MAXG][lane], 64}, {&tmp[2 * MAXG][lane], 64},
+                                {&tmp[3 * MAXG][lane], 64}, {&tmp[4 * MAXG][lane], 64}};
     const int nsteps = P.nd + P.na;
     // one pass: a lane's ops go to an LDS staging column first (their position in the program is known only once every
     // lane has counted its own), then a wave scan places them

@@ -138,18 +138,24 @@ MCCNN_PROG_HD void patch_setup(const Layout &L, const uint32_t *sup0, int H, int
 
 // Per-row work arrays with run-time indices: plain stack arrays on the host, strided LDS on the device (private
 // "scratch" arrays cost a ~300-clock memory round trip per access there).
-struct Arr {
-    int *p;
+template <class T>
+struct ArrT {
+    T *p;
     int s;
-    MCCNN_PROG_HD int &operator[](int i) const { return p[i * s]; }
+    MCCNN_PROG_HD T &operator[](int i) const { return p[i * s]; }
 };
-struct RowTmp {
-    Arr aset, cols, l, r, acols;
+// every entry is an anchor-row set (< 2^MAXK), a column index or an arm length: bytes on the device (10 KB of LDS per
+// wave as ints kept the builder at two waves per SIMD), ints on the host
+template <class T>
+struct RowTmpT {
+    ArrT<T> aset, cols, l, r, acols;
 };
+using Arr = ArrT<int>;
+using RowTmp = RowTmpT<int>;
 
 // The ops of sweep step t (one region row): its windows and arm runs, in execution order.
-template <class E>
-MCCNN_PROG_HD void emit_row(const Layout &L, const Patch &P, const uint32_t *sup0, int W, int t, const RowTmp &T, E &e)
+template <class E, class TT>
+MCCNN_PROG_HD void emit_row(const Layout &L, const Patch &P, const uint32_t *sup0, int W, int t, const RowTmpT<TT> &T, E &e)
 {
     // every scalar of the layout and of the patch into registers first: on the device both live in LDS, next to the work
     // arrays this function writes, so the compiler would otherwise reload them after every store
@@ -159,27 +165,27 @@ MCCNN_PROG_HD void emit_row(const Layout &L, const Patch &P, const uint32_t *sup
     {
         const int yq = t < nd ? y0 + K - 1 - t : y0 + 1 + (t - nd);
         // anchors taking part in this step
-        const Arr aset = T.aset, cols = T.cols;
+        const ArrT<TT> aset = T.aset, cols = T.cols;
         int ncols = 0;
         for (int j = 0; j < G; ++j) {
             int m = 0;
             for (int k = 0; k < K; ++k) m |= (int)((P.sched[k][j] >> t) & 1ull) << k;
-            aset[j] = m;
-            if (m) cols[ncols++] = j;
+            aset[j] = (TT)m;
+            if (m) cols[ncols++] = (TT)j;
         }
         if (ncols == 0) return;
-        const Arr l = T.l, r = T.r;
+        const ArrT<TT> l = T.l, r = T.r;
         // the row's G support words: unconditional, independent loads (words right of the image are never used and lie
-        // inside the support buffer, whose derived planes follow plane 0)
-        for (int j = 0; j < G; ++j) l[j] = (int)sup0[(size_t)yq * W + x0 + j];
+        // inside the support buffer, whose derived planes follow plane 0); their arm lengths, clamped to R
+        for (int j = 0; j < G; ++j) {
+            const uint32_t a = sup0[(size_t)yq * W + x0 + j];
+            const int lj = (int)((a >> 10) & 31u), rj = (int)((a >> 15) & 31u);
+            l[j] = (TT)(lj > R ? R : lj);
+            r[j] = (TT)(rj > R ? R : rj);
+        }
         int lo = 1 << 30, hi = -1, maxl = 0, maxr = 0;
         for (int i = 0; i < ncols; ++i) {
             const int j = cols[i];
-            const uint32_t a = (uint32_t)l[j];
-            l[j] = (int)((a >> 10) & 31u);
-            r[j] = (int)((a >> 15) & 31u);
-            if (l[j] > R) l[j] = R;
-            if (r[j] > R) r[j] = R;
             const int c = j + R;
             if (c - l[j] < lo) lo = c - l[j];
             if (c + r[j] > hi) hi = c + r[j];
@@ -243,7 +249,7 @@ MCCNN_PROG_HD void emit_row(const Layout &L, const Patch &P, const uint32_t *sup
             for (int q = 0; q < cnt; ++q) run(cols[i + q], glo, cols[i + q] + R, l[cols[i + q]] + 1, 0);
             i += cnt;
         }
-        const Arr acols = T.acols;
+        const ArrT<TT> acols = T.acols;
         int nac = 0;
         for (int i = 0; i < ncols; ++i)
             if (r[cols[i]]) acols[nac++] = cols[i];
