@@ -123,6 +123,21 @@ def cost_volume_aggregation(left_image, right_image, left_cost_volume, right_cos
     was_np = False
     images = [_img(left_image)[0], _img(right_image)[0]]
     supports = [sd.cross_arms(img, intensity_threshold, int(distance_threshold)) for img in images]
+    if not CBCA_BOTH_VIEWS and CBCA_ORDER == "reference" and int(distance_threshold) <= 14:
+        # What match.py's default runs: the reference's summation order on pixel-major copies, both views per launch,
+        # through the program-driven assembly kernel (its programs are built once here and serve every iteration; from
+        # the third iteration on the pixels whose support region is the pixel itself are left alone - same bits).
+        vl, was_np = _dev(left_cost_volume)
+        vr, _ = _dev(right_cost_volume)
+        D, H, W = vl.shape
+        progs = sd.cbca_prog_buffers(D, H, W, vl.device) if tuple(vr.shape) == (D, H, W) else None
+        if progs is not None:
+            sd.cbca_prog_build_pair(supports[0], supports[1], D, int(distance_threshold), progs,
+                                    "both" if int(max_average_time) > 2 else "full")
+            hl, hr = sd.dhw_to_hwd(vl), sd.dhw_to_hwd(vr)       # copies: the caller's arrays stay as they are
+            (rl, _), (rr, _) = sd.cbca_prog_pair(hl, torch.empty_like(hl), supports[0], hr, torch.empty_like(hr),
+                                                 supports[1], progs, D, int(max_average_time), int(distance_threshold))
+            return _ret(sd.hwd_to_dhw(rl, D), was_np), _ret(sd.hwd_to_dhw(rr, D), was_np)
     for k, vol in enumerate((left_cost_volume, right_cost_volume)):
         v, was_np = _dev(vol)
         if torch.is_tensor(vol) and v.data_ptr() == vol.data_ptr():
