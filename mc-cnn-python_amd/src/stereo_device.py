@@ -730,23 +730,28 @@ class StereoMatcher(object):
         b0, b1, b2, b3 = ws["vol"]
         sides = [hip.MCCNN_SIDE_LEFT, hip.MCCNN_SIDE_RIGHT]
 
-        # The support arms depend on the images only: without per-stage timing they run on a side stream under the
-        # conv stack (a latency-bound pair of small launches beside matrix-core work) and join before the first CBCA
+        # The support arms and the aggregation programs depend on the images only: without per-stage timing they run
+        # on a side stream - arms + full programs beside the cost volume, the skip programs (first needed by the third
+        # iteration of the second aggregation) beside the first aggregation and SGM.  Measured at cfg2 (one box, 100
+        # pairs each, twice): everything on the main stream 9.22 / 9.22 ms, everything beside the conv stack 9.19 /
+        # 9.12 (the builder's waves slow the matrix-core kernels down by what they save), this placement 9.14 / 9.06.
         overlap = timer is _NO_TIMER
-        if overlap:
+        skip_ready = full_ready = sup_l = sup_r = None
+
+        def side_work(stage):
+            """stage 0: support arms + the full programs; stage 1: the skip programs."""
+            nonlocal skip_ready, full_ready, sup_l, sup_r
             if self._side is None:
                 self._side = torch.cuda.Stream()
-            main = torch.cuda.current_stream()
-            self._side.wait_stream(main)
-            skip_ready = None
+            self._side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._side):
-                sup_l, sup_r = cross_arms_pair(L, R, hp["cbca_intensity"], hp["cbca_distance"], ws["sup_l"], ws["sup_r"])
-                if ws["progs"] is not None:
-                    cbca_prog_build_pair(sup_l, sup_r, D, hp["cbca_distance"], ws["progs"], "full")
+                if stage == 0:
+                    sup_l, sup_r = cross_arms_pair(L, R, hp["cbca_intensity"], hp["cbca_distance"], ws["sup_l"], ws["sup_r"])
+                    if ws["progs"] is not None:
+                        cbca_prog_build_pair(sup_l, sup_r, D, hp["cbca_distance"], ws["progs"], "full")
                     full_ready = torch.cuda.Event()
                     full_ready.record(self._side)
-                    # the second program set is first needed by the third iteration of the second aggregation: it is
-                    # built beside the first aggregation and SGM (bandwidth-bound kernels; the builder is latency-bound)
+                elif ws["progs"] is not None:
                     cbca_prog_build_pair(sup_l, sup_r, D, hp["cbca_distance"], ws["progs"], "skip")
                     skip_ready = torch.cuda.Event()
                     skip_ready.record(self._side)
@@ -757,6 +762,8 @@ class StereoMatcher(object):
         else:
             fl, fr = self.net.features_pair_hwc(L, R, tile_rows=self.feature_tile_rows)
         timer.stop()
+        if overlap:
+            side_work(0)
 
         # the bit-exact variant writes its cost volume pixel-major right away (nothing converts layouts after that)
         direct = self.pixel_major() and self.cv_mode == hip.MCCNN_CV_EXACT and D <= 512
@@ -771,10 +778,9 @@ class StereoMatcher(object):
             keep["cv"] = (hwd_to_dhw(lh, D), hwd_to_dhw(rh, D)) if direct else (lcv.clone(), rcv.clone())
 
         if overlap:
-            if skip_ready is not None:
-                torch.cuda.current_stream().wait_event(full_ready)
-            else:
-                torch.cuda.current_stream().wait_stream(self._side)
+            torch.cuda.current_stream().wait_event(full_ready)
+            if ws["progs"] is not None:
+                side_work(1)
         else:
             timer.start("cross_arms")
             sup_l, sup_r = cross_arms_pair(L, R, hp["cbca_intensity"], hp["cbca_distance"], ws["sup_l"], ws["sup_r"])
