@@ -382,14 +382,16 @@ def main():
         "sgm_first_pass": 2 * 2 * vol_bytes,
     }
     # Iterations 3.. of an aggregation leave the pixels alone whose support region is the pixel itself (their value is
-    # a fixed point: mccnn_cbca_iter_prog_pair_skip, include/mccnn.h): the units such a launch processes are the OTHER
-    # pixels' voxels, so its algorithmic bytes are 8 B x those - counted from the support planes of the timed pair
+    # a fixed point: mccnn_cbca_iter_prog_pair_skip, include/mccnn.h).  SURVEY 8d prices a CBCA iteration at 8 B per
+    # voxel and volume whatever the implementation avoids ("a cache-resident CBCA may legitimately exceed 100 %; report
+    # rocprof HBM bytes alongside"): so does `algorithmic_bytes_per_launch`; the entry also carries the stricter figure
+    # on the voxels such a launch actually processes, counted from the support planes of the timed pair.
     unit_fraction = None
+    algo["cbca_iter_prog_pair_skip"] = 2 * 2 * vol_bytes
     if "cbca_iter_prog_pair_skip" in stages:
         ws = matcher.workspace(H, W, D)
         unit = [float(((ws[k] & 0xfffff) == 0).float().mean().item()) for k in ("sup_l", "sup_r")]
         unit_fraction = {"left": round(unit[0], 4), "right": round(unit[1], 4)}
-        algo["cbca_iter_prog_pair_skip"] = 2 * vol_bytes * ((1.0 - unit[0]) + (1.0 - unit[1]))
     traffic = traffic_table(args.config)
     rooflines = {}
     for k, b in algo.items():
@@ -403,12 +405,14 @@ def main():
                             "algorithmic_bytes_per_launch": int(b)}
     if unit_fraction is not None:
         r = rooflines["cbca_iter_prog_pair_skip"]
+        processed = 2 * vol_bytes * ((1.0 - unit[0]) + (1.0 - unit[1]))
         r["unit_region_pixels"] = unit_fraction
-        r["note"] = ("third and later iterations: pixels whose support region is the pixel itself are fixed points and are "
-                     "neither read for their own sake nor written; algorithmic bytes = 8 B per voxel of the other pixels "
-                     "(every voxel counted, like a full iteration: %.1f GB/s = %.4f of peak)"
-                     % (4 * vol_bytes / (stages["cbca_iter_prog_pair_skip"] * 1e-3) / 1e9,
-                        4 * vol_bytes / (stages["cbca_iter_prog_pair_skip"] * 1e-3) / 1e9 / HBM_PEAK_GBS))
+        r["processed_voxel_bytes_per_launch"] = int(processed)
+        r["frac_on_processed_voxels"] = round(processed / (stages["cbca_iter_prog_pair_skip"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        r["note"] = ("third and later iterations of an aggregation: pixels whose support region is the pixel itself are "
+                     "fixed points and are neither read for their own sake nor written (same bits); algorithmic bytes = "
+                     "SURVEY 8d's 8 B per voxel and volume, `traffic` = the HBM bytes rocprofv3 counted, "
+                     "`frac_on_processed_voxels` prices only the voxels of the other pixels")
     dominant = max(rooflines, key=lambda k: per_step[k]) if rooflines else None
     # SGM as a stage (what north_star's >= 50 % target is quoted on): 4 passes + the two layout changes
     sgm_stage_ms = (per_step.get("sgm_pass", 0.0) + per_step.get("sgm_first_pass", 0.0) +
