@@ -216,6 +216,24 @@ def test_unit_regions_are_fixed_points_after_one_iteration_including_negative_ze
     assert np.array_equal(v1[:, unit][~nan & (vol[:, unit] != 0)], vol[:, unit][~nan & (vol[:, unit] != 0)])
 
 
+def test_unit_region_fixed_point_for_every_kind_of_float32():
+    """The arithmetic fact itself, on two million random bit patterns plus the special encodings: with aver_num = 1 the
+    reference computes y = (0 + x) / 1 (pf:156-161, float32); y differs from x only for -0.0 and signalling NaNs, and
+    (0 + y) / 1 == y bit for bit - so a pixel whose region is the pixel itself stops changing after one iteration."""
+    rng = np.random.default_rng(5)
+    bits = np.concatenate([rng.integers(0, 2 ** 32, 2_000_000, dtype=np.uint64).astype(np.uint32),
+                           np.array([0x00000000, 0x80000000, 0x7f800000, 0xff800000, 0x7fc00000, 0xffc00000, 0x7f800001,
+                                     0xff812345, 0x00000001, 0x80000001, 0x007fffff, 0x7f7fffff, 0xff7fffff], np.uint32)])
+    x = bits.view(np.float32)
+    with np.errstate(invalid="ignore"):
+        y = ((np.float32(0) + x) / np.float32(1)).astype(np.float32)
+        z = ((np.float32(0) + y) / np.float32(1)).astype(np.float32)
+    assert np.array_equal(y.view(np.uint32), z.view(np.uint32))
+    changed = y.view(np.uint32) != bits
+    quiet = bits | np.uint32(0x00400000)
+    assert np.all((bits[changed] == 0x80000000) | (np.isnan(x[changed]) & (y.view(np.uint32)[changed] == quiet[changed])))
+
+
 def test_generated_kernel_with_scalar_prefetch_in_the_simulator():
     """The L2 warm-up loads never leave the volume (the simulator faults on any access outside an allocation)."""
     for (H, W, D, pf) in ((12, 17, 8, 5), (9, 33, 4, 20), (11, 16, 6, 10)):
