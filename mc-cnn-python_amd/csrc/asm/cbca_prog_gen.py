@@ -84,10 +84,12 @@ def _fmt(x):
 SOPP = {"s_waitcnt", "s_branch", "s_cbranch_scc0", "s_cbranch_scc1", "s_cbranch_vccz", "s_cbranch_vccnz", "s_nop",
         "s_endpgm", "s_set_gpr_idx_off", "s_barrier", "s_cbranch_execz"}
 SOPK = {"s_movk_i32"}
+# (s_bfe_u32 with its literal is 8 bytes by the generic rule)
 SMEM = {"s_load_dword", "s_load_dwordx2", "s_load_dwordx4", "s_load_dwordx8", "s_load_dwordx16"}
 VOP3 = {"v_cmp_lt_f32_e64", "v_cmp_eq_f32_e64", "v_pk_add_f32", "v_readlane_b32", "v_fma_f32", "v_div_scale_f32", "v_div_fmas_f32", "v_div_fixup_f32", "v_mul_lo_u32",
         "v_mad_u32_u24", "v_cndmask_b32_e64", "v_cmp_lt_f32_e64", "v_cmp_eq_f32_e64", "v_cmp_gt_u32_e64",
         "v_min3_f32", "v_lshl_add_u32"}
+DS = {"ds_read_b32", "ds_read_b64", "ds_read_b96", "ds_read_b128"}
 MUBUF = {"buffer_load_dword", "buffer_load_dwordx2", "buffer_load_dwordx3", "buffer_load_dwordx4",
          "buffer_store_dword", "buffer_store_dwordx2", "buffer_store_dwordx3", "buffer_store_dwordx4"}
 FLOAT_INLINE = {0.0, 0.5, 1.0, 2.0, 4.0, -0.5, -1.0, -2.0, -4.0}
@@ -107,7 +109,7 @@ def ins_size(i):
         return 0
     if i.op in SOPP or i.op in SOPK:
         return 4
-    if i.op in SMEM or i.op in VOP3 or i.op in MUBUF:
+    if i.op in SMEM or i.op in VOP3 or i.op in MUBUF or i.op in DS:
         return 8
     if i.mods.get("dpp"):
         return 8
@@ -117,7 +119,7 @@ def ins_size(i):
 
 
 class Params:
-    def __init__(self, vpl=4, K=2, G=5, W=12, NB=1, PF=0, wta=False, debug=0, order=0, minvgpr=0, skip=False):
+    def __init__(self, vpl=4, K=2, G=5, W=12, NB=1, PF=0, wta=False, debug=0, order=0, minvgpr=0, skip=False, ring=0, persist=False):
         assert K in (1, 2, 4, 8), "anchor sets are aligned power-of-two groups of anchor rows"
         assert K * G <= 20, "the region sizes of the K x G anchors live in s[16:35]"
         self.VPL, self.K, self.G, self.W, self.NB, self.PF, self.wta, self.debug = vpl, K, G, W, NB, PF, wta, debug
@@ -138,6 +140,23 @@ class Params:
         self.nvgpr = self.PHYS_WIN + NB * W * self.RS      # NB windows: the next one loads under the current one's adds
         self.nvgpr_alloc = max(self.nvgpr, minvgpr)        # experiments: a larger allocation = fewer waves per SIMD
         self.NWAIT = W + 1                          # WAIT handlers 0 .. W
+        # ring (experimental, tools/dev_prog_check.py --ring S): the window rows travel through an LDS ring of S 1-KiB
+        # slots per wave - PF ops stream upcoming units into it with buffer_load ... lds (no registers), CP ops copy a
+        # unit into the register window when its turn comes: several windows in flight per wave
+        self.ring = ring
+        # persist (experimental, with ring): 8 x NWC x band_groups waves, each walks the column groups cg0, cg0 + NWC, ..
+        # of its own row group for every (image, chunk); the next patch's program is fetched while the current one ends
+        self.persist = persist
+        assert not persist or (ring and not wta), "the persistent loop is built on the ring kernels"
+        if ring:
+            assert NB == 1 and ring >= W, "a unit must fit the ring"
+            self.NWAIT = 64
+            self.v_lane16, self.v_lds = self.nvgpr, self.nvgpr + 1
+            self.nvgpr += 2
+            if persist:
+                self.v_nextA, self.v_nextB = self.nvgpr, self.nvgpr + 1
+                self.nvgpr += 2
+            self.nvgpr_alloc = max(self.nvgpr, minvgpr)
 
     def acc(self, k, j, c=0):
         return (k * self.G + j) * self.RS + c
@@ -181,6 +200,9 @@ S = dict(
     D=88, store1=89,
     dispp=96,          # s[96:97]
     dump=98, pfoff=99,
+    ring_head=90, ring_tail=91, ring_t=92,
+    nwc=93, cg=94, z=95, rg=36, cg0=37, prg=38, guard=39, band=78, cgn=79,
+    rs_pn=84,          # s[84:87] (persist): descriptor of the next patch's program
     pfa=100,           # s[100:101]
 )
 NSGPR = 102
@@ -225,7 +247,11 @@ class Gen:
         e = self.e
         e("v_readlane_b32", sreg(S["op"]), vreg(self.P.v_progA), sreg(S["i"]))
         e("s_add_u32", sreg(S["i"]), sreg(S["i"]), 1)
-        e("s_sext_i32_i16", sreg(S["t"]), sreg(S["op"]))
+        if self.P.ring:       # (experimental kernels are larger than 32 KiB: handler offsets in dwords, unsigned)
+            e("s_bfe_u32", sreg(S["t"]), sreg(S["op"]), 0x100000)
+            e("s_lshl_b32", sreg(S["t"]), sreg(S["t"]), 2)
+        else:
+            e("s_sext_i32_i16", sreg(S["t"]), sreg(S["op"]))
         e("s_lshr_b32", "m0", sreg(S["op"]), 16)
         e("s_add_u32", sreg(S["pc"]), sreg(S["base"]), sreg(S["t"]))
         e("s_addc_u32", sreg(S["pc"] + 1), sreg(S["base"] + 1), 0)
@@ -249,6 +275,160 @@ class Gen:
         K, G, VPL, W = P.K, P.G, P.VPL, P.W
         s = lambda n, c=1: sreg(S[n], c) if isinstance(n, str) else sreg(n, c)
         self.label("entry")
+        if P.persist:
+            self.prologue_persist()
+        else:
+            self.prologue_once()
+        self.label("code_base")
+        self.handlers()
+        self.end_handler()
+        return self
+
+    def prologue_persist(self):
+        P, e = self.P, self.e
+        K, G, VPL, W = P.K, P.G, P.VPL, P.W
+        s = lambda n, c=1: sreg(S[n], c) if isinstance(n, str) else sreg(n, c)
+        e("s_load_dwordx8", s("Dp", 8), s("karg", 2), 0x40)
+        e("s_load_dword", s("nwc"), s("karg", 2), 0x60)
+        e("s_waitcnt", "lgkmcnt(0)")
+        e("s_max_u32", s("nwc"), s("nwc"), 1)
+        e("s_and_b32", s("band"), s("bx"), 7)
+        e("s_lshr_b32", s("rg"), s("bx"), 3)
+        e("s_mov_b32", s("cg0"), 0)
+        self.label("p_div")                                              # rg = wl % band_groups, cg0 = wl / band_groups
+        e("s_cmp_lt_u32", s("rg"), s("band_groups"))
+        e("s_cbranch_scc1", "p_divd")
+        e("s_sub_u32", s("rg"), s("rg"), s("band_groups"))
+        e("s_add_u32", s("cg0"), s("cg0"), 1)
+        e("s_branch", "p_div")
+        self.label("p_divd")
+        e("s_mul_i32", s("y0"), s("band"), s("band_rows"))
+        e("s_mul_i32", s("t2"), s("rg"), K)
+        e("s_add_u32", s("y0"), s("y0"), s("t2"))
+        e("s_cmp_ge_i32", s("y0"), s("H"))
+        e("s_cbranch_scc1", "done")
+        e("s_mul_i32", s("prg"), s("band"), s("band_groups"))
+        e("s_add_u32", s("prg"), s("prg"), s("rg"), comment="patch row group")
+        e("v_lshlrev_b32", vreg(P.v_lane4), 2, "v0")
+        e("v_lshlrev_b32", vreg(P.v_lane16), 4, "v0")
+        e("v_mov_b32", vreg(P.v_lds), "v0", comment="lane id (v0 becomes an accumulator)")
+        e("s_lshl_b32", s("pix"), s("Dp"), 2)
+        e("s_getpc_b64", s("base", 2))
+        self.label("after_getpc")
+        e("s_add_u32", s("base"), s("base"), "code_base-after_getpc")
+        e("s_addc_u32", sreg(S["base"] + 1), sreg(S["base"] + 1), 0)
+        e("s_mov_b32", s("safe_m0"), M0_SRC1)
+        e("s_mov_b32", s("z"), 0)
+        # a hard bound on the patches a wave may walk: (ngroups + 1) * 2 * nchunks
+        e("s_add_u32", s("guard"), s("ngroups"), 1)
+        e("s_mul_i32", s("guard"), s("guard"), s("nchunks"))
+        e("s_lshl_b32", s("guard"), s("guard"), 1)
+        # ---- per (image, chunk) ------------------------------------------------------------------------------------------
+        self.label("p_z")
+        e("s_lshl_b32", s("t0"), s("nchunks"), 1)
+        e("s_cmp_ge_u32", s("z"), s("t0"))
+        e("s_cbranch_scc1", "done")
+        e("s_load_dwordx16", s("ka", 16), s("karg", 2), 0x0)
+        e("s_waitcnt", "lgkmcnt(0)")
+        e("s_cmp_ge_u32", s("z"), s("nchunks"))
+        e("s_cselect_b32", s("job"), 1, 0)
+        e("s_cselect_b32", s("t1"), s("nchunks"), 0)
+        e("s_cselect_b64", s("inp", 2), sreg(S["ka"] + 2, 2), sreg(S["ka"] + 0, 2))
+        e("s_cselect_b64", s("outp", 2), sreg(S["ka"] + 6, 2), sreg(S["ka"] + 4, 2))
+        e("s_cselect_b64", s("progp", 2), sreg(S["ka"] + 10, 2), sreg(S["ka"] + 8, 2))
+        e("s_cselect_b64", s("supp", 2), sreg(S["ka"] + 14, 2), sreg(S["ka"] + 12, 2))
+        e("s_sub_u32", s("chunk"), s("z"), s("t1"))
+        # voff = d0 * 4 with d0 = (chunk * 64 + lane) * VPL, or kDrop past the disparity range
+        e("s_lshl_b32", s("t1"), s("chunk"), 6)
+        vt = P.PHYS_WIN
+        e("v_add_u32", vreg(vt), s("t1"), vreg(P.v_lds))
+        e("v_mul_u32_u24", vreg(vt), 4 * VPL, vreg(vt))
+        e("v_mov_b32", vreg(P.v_voff), KDROP)
+        e("v_cmp_gt_u32", "vcc", s("pix"), vreg(vt))
+        e("v_cndmask_b32", vreg(P.v_voff), vreg(P.v_voff), vreg(vt), "vcc")
+        # input rows any arm of this wave's patches can reach (the same for every column group)
+        e("s_sub_u32", s("t0"), s("y0"), R)
+        e("s_max_i32", s("t0"), s("t0"), 0, comment="row0")
+        e("s_sub_u32", s("t3"), s("H"), 1)
+        e("s_add_u32", s("t1"), s("y0"), K - 1)
+        e("s_min_i32", s("t1"), s("t1"), s("t3"))
+        e("s_add_u32", s("t1"), s("t1"), R)
+        e("s_min_i32", s("t1"), s("t1"), s("t3"), comment="row1")
+        e("s_sub_u32", s("t1"), s("t1"), s("t0"))
+        e("s_add_u32", s("t1"), s("t1"), 1, comment="rows")
+        e("s_mul_i32", s("t2"), s("W"), s("pix"), comment="bytes per image row")
+        e("s_mul_i32", sreg(S["rs_in"] + 2), s("t1"), s("t2"))
+        e("s_mul_hi_u32", s("t4"), s("t0"), s("t2"))
+        e("s_mul_i32", s("t3"), s("t0"), s("t2"))
+        e("s_add_u32", s("rs_in"), s("inp"), s("t3"))
+        e("s_addc_u32", sreg(S["rs_in"] + 1), sreg(S["inp"] + 1), s("t4"))
+        e("s_and_b32", sreg(S["rs_in"] + 1), sreg(S["rs_in"] + 1), 0xffff)
+        e("s_mov_b32", sreg(S["rs_in"] + 3), 0x00020000)
+        # the first patch of this (image, chunk): its program is fetched here, the later ones at the end of their forerunner
+        e("s_mov_b32", s("cg"), s("cg0"))
+        e("s_cmp_ge_u32", s("cg"), s("ngroups"))
+        e("s_cbranch_scc1", "p_nextz")
+        e("s_mov_b32", s("cgn"), s("cg"))
+        self.next_program_fetch()
+        self.label("p_patch")                                             # rs_pn / cgn describe the patch that starts now
+        e("s_sub_u32", s("guard"), s("guard"), 1)
+        e("s_cmp_le_i32", s("guard"), 0)
+        e("s_cbranch_scc1", "done")
+        e("s_mov_b32", s("cg"), s("cgn"))
+        e("s_mul_i32", s("x0"), s("cg"), G)
+        for q in range(4):
+            e("s_mov_b32", sreg(S["rs_prog"] + q), sreg(S["rs_pn"] + q))
+        self.cnt_loads()
+        for r in range(P.nacc):
+            e("v_mov_b32", vreg(r), 0)
+        e("s_movk_i32", s("progoff"), 512)
+        e("s_mov_b32", s("ring_head"), 0)
+        e("s_mov_b32", s("ring_tail"), 0)
+        e("s_mov_b32", s("i"), 0)
+        e("s_waitcnt", "vmcnt(0)")
+        e("v_mov_b32", vreg(P.v_progA), vreg(P.v_nextA))
+        e("v_mov_b32", vreg(P.v_progB), vreg(P.v_nextB))
+        e("s_set_gpr_idx_on", s("i"), "gpr_idx(SRC1)")
+        self.tail()
+        self.label("p_nextz")
+        e("s_add_u32", s("z"), s("z"), 1)
+        e("s_branch", "p_z")
+
+    def next_program_fetch(self):
+        """Descriptor rs_pn of patch (prg, cgn) and its first two 64-op chunks into nextA / nextB."""
+        P, e = self.P, self.e
+        s = lambda n, c=1: sreg(S[n], c) if isinstance(n, str) else sreg(n, c)
+        e("s_mul_i32", s("t0"), s("prg"), s("ngroups"))
+        e("s_add_u32", s("t0"), s("t0"), s("cgn"), comment="patch index")
+        e("s_mul_hi_u32", s("t2"), s("t0"), s("prog_stride"))
+        e("s_mul_i32", s("t1"), s("t0"), s("prog_stride"))
+        e("s_add_u32", s("rs_pn"), s("progp"), s("t1"))
+        e("s_addc_u32", sreg(S["rs_pn"] + 1), sreg(S["progp"] + 1), s("t2"))
+        e("s_and_b32", sreg(S["rs_pn"] + 1), sreg(S["rs_pn"] + 1), 0xffff)
+        e("s_mov_b32", sreg(S["rs_pn"] + 2), s("prog_stride"))
+        e("s_mov_b32", sreg(S["rs_pn"] + 3), 0x00020000)
+        e("buffer_load_dword", vreg(P.v_nextA), vreg(P.v_lane4), s("rs_pn", 4), 0, offen=True)
+        e("buffer_load_dword", vreg(P.v_nextB), vreg(P.v_lane4), s("rs_pn", 4), 0, offen=True, offset=256)
+
+    def cnt_loads(self):
+        P, e = self.P, self.e
+        s = lambda n, c=1: sreg(S[n], c) if isinstance(n, str) else sreg(n, c)
+        e("s_sub_u32", s("t3"), s("H"), 1)
+        for k in range(P.K):
+            e("s_add_u32", s("t0"), s("y0"), k)
+            e("s_min_i32", s("t0"), s("t0"), s("t3"))
+            e("s_mul_i32", s("t0"), s("t0"), s("W"))
+            e("s_add_u32", s("t0"), s("t0"), s("x0"))
+            e("s_lshl_b32", s("t0"), s("t0"), 2)
+            e("s_add_u32", s("t4"), s("supp"), s("t0"))
+            e("s_addc_u32", s("t5"), sreg(S["supp"] + 1), 0)
+            for j in range(P.G):
+                e("s_load_dword", sreg(S["cnt"] + k * P.G + j), sreg(S["t4"], 2), 4 * j)
+
+    def prologue_once(self):
+        P, e = self.P, self.e
+        K, G, VPL, W = P.K, P.G, P.VPL, P.W
+        s = lambda n, c=1: sreg(S[n], c) if isinstance(n, str) else sreg(n, c)
         e("s_load_dwordx16", s("ka", 16), s("karg", 2), 0x0)
         e("s_load_dwordx8", s("Dp", 8), s("karg", 2), 0x40)
         if P.wta:
@@ -296,6 +476,10 @@ class Gen:
         e("buffer_load_dword", vreg(P.v_progA), vreg(P.v_lane4), s("rs_prog", 4), 0, offen=True)
         e("buffer_load_dword", vreg(P.v_progB), vreg(P.v_lane4), s("rs_prog", 4), 0, offen=True, offset=256)
         e("s_movk_i32", s("progoff"), 512)
+        if P.ring:
+            e("v_lshlrev_b32", vreg(P.v_lane16), 4, "v0", comment="lane * 16: this lane's bytes of an LDS slot")
+            e("s_mov_b32", s("ring_head"), 0)
+            e("s_mov_b32", s("ring_tail"), 0)
         # region sizes of the K x G anchors for the END handler (rows clamped to the image; words past the right edge are
         # never used), requested here so that they arrive under the program: the kernarg registers they land in are dead
         e("s_sub_u32", s("t3"), s("H"), 1)
@@ -351,7 +535,10 @@ class Gen:
         e("s_set_gpr_idx_on", s("i"), "gpr_idx(SRC1)", comment="index mode on for the whole program: M0 = 0x2000 | idx")
         self.tail()
 
-        self.label("code_base")
+    def handlers(self):
+        P, e = self.P, self.e
+        K, G, VPL, W = P.K, P.G, P.VPL, P.W
+        s = lambda n, c=1: sreg(S[n], c) if isinstance(n, str) else sreg(n, c)
         # ---- ADD lines: (column j, anchor set 1 = row 0 / 2 = row 1 / 3 = both, direction) ---------------------------
         self.lines = {}
         for j in range(G):
@@ -398,6 +585,50 @@ class Gen:
             self.label("wait_%d" % k)
             e("s_waitcnt", "vmcnt(%d)" % k)
             self.tail()
+        if P.ring:
+            SB = 256 * VPL                                               # bytes of a ring slot
+            RB = P.ring * SB
+            # ---- PF n: n consecutive pixels ending at pixel index p (the parameter) -> the next n ring slots.  The ring
+            # head is kept here exactly as the builder keeps it: a unit that does not fit behind the head starts at 0.
+            for n in range(1, W + 1):
+                self.label("pf_n%d" % n)
+                e("s_mul_i32", s("so"), "m0", s("pix"))
+                e("s_add_u32", s("ring_t"), s("ring_head"), n * SB)
+                e("s_cmp_gt_u32", s("ring_t"), RB)
+                e("s_cselect_b32", s("ring_head"), 0, s("ring_head"))
+                e("s_set_gpr_idx_off")
+                e("s_add_u32", "m0", s("ring_head"), (n - 1) * SB, comment="LDS address of slot n - 1")
+                e("s_add_u32", s("ring_head"), s("ring_head"), n * SB)
+                if n != W:
+                    e("s_branch", "pf_blk%d" % n)
+            for n in range(W, 0, -1):
+                self.label("pf_blk%d" % n)
+                op = {1: "buffer_load_dword", 2: "buffer_load_dwordx2", 3: "buffer_load_dwordx3", 4: "buffer_load_dwordx4"}[VPL]
+                e(op, vreg(P.v_voff), s("rs_in", 4), s("so"), offen=True, lds=True)
+                if n > 1:
+                    e("s_sub_u32", s("so"), s("so"), s("pix"))
+                    e("s_sub_u32", "m0", "m0", SB)
+            e("s_mov_b32", "m0", s("safe_m0"))
+            e("s_set_gpr_idx_on", s("ring_t"), "gpr_idx(SRC1)", comment="(the dispatcher sets M0 from the next op)")
+            e("s_mov_b32", "m0", s("safe_m0"))
+            self.tail()
+            # ---- CP n: the oldest n ring slots -> window slots 0 .. n - 1 (the WAIT op in front of it has let them arrive)
+            for n in range(1, W + 1):
+                self.label("cp_n%d" % n)
+                e("s_mov_b32", "m0", s("safe_m0"))
+                e("s_add_u32", s("ring_t"), s("ring_tail"), n * SB)
+                e("s_cmp_gt_u32", s("ring_t"), RB)
+                e("s_cselect_b32", s("ring_tail"), 0, s("ring_tail"))
+                e("v_add_u32", vreg(P.v_lds), s("ring_tail"), vreg(P.v_lane16))
+                e("s_add_u32", s("ring_tail"), s("ring_tail"), n * SB)
+                if n != W:
+                    e("s_branch", "cp_blk%d" % n)
+            rd = {1: "ds_read_b32", 2: "ds_read_b64", 3: "ds_read_b96", 4: "ds_read_b128"}[VPL]
+            for n in range(W, 0, -1):
+                self.label("cp_blk%d" % n)
+                e(rd, vreg(P.PHYS_WIN + P.RS * (n - 1), VPL), vreg(P.v_lds), offset=(n - 1) * SB)
+            e("s_waitcnt", "lgkmcnt(0)")
+            self.tail()
         # ---- REFILL -----------------------------------------------------------------------------------------------------------
         self.label("refill")
         e("s_waitcnt", "vmcnt(0)")
@@ -406,9 +637,20 @@ class Gen:
         e("s_add_u32", s("progoff"), s("progoff"), 256)
         e("s_mov_b32", s("i"), 0)
         self.tail()
+
+    def end_handler(self):
+        P, e = self.P, self.e
+        K, G, VPL, W = P.K, P.G, P.VPL, P.W
+        s = lambda n, c=1: sreg(S[n], c) if isinstance(n, str) else sreg(n, c)
         # ---- END: pf:161 -------------------------------------------------------------------------------------------------------
         self.label("end")
         e("s_set_gpr_idx_off")
+        if P.persist:     # the next patch of this wave: its program travels under the divisions and the stores
+            e("s_add_u32", s("cgn"), s("cg"), s("nwc"))
+            e("s_cmp_ge_u32", s("cgn"), s("ngroups"))
+            e("s_cbranch_scc1", "e_nofetch")
+            self.next_program_fetch()
+            self.label("e_nofetch")
         e("s_waitcnt", "lgkmcnt(0)", comment="the region sizes, requested in the prologue")
         T = P.PHYS_WIN                                                  # the window is dead: temporaries
         assert P.W * P.RS >= 1 + 5 * VPL, "the division's temporaries live in the window registers"
@@ -495,9 +737,12 @@ class Gen:
                     e("s_add_u32", s("so"), s("so"), s("pix"))
         if P.wta:
             self.wta_tail()
+        if P.persist:
+            e("s_cmp_ge_u32", s("cgn"), s("ngroups"))
+            e("s_cbranch_scc1", "p_nextz")
+            e("s_branch", "p_patch")
         self.label("done")
         e("s_endpgm")
-        return self
 
     # a7 fused into the last iteration (pf:245-254): the first strict minimum over d of every result pixel - the two
     # wave reductions of wta_hwd_kernel (cbca_hwd.hip) on the quotients the wave still holds: the minimum, then the
@@ -624,15 +869,20 @@ class Gen:
         P = self.P
         o = self.offsets()
         base = o["code_base"]
-        L = dict(VPL=P.VPL, RS=P.RS, K=P.K, G=P.G, W=P.W, MAXD=P.MAXD, MAXA=P.MAXA, R=R, NWAIT=P.NWAIT, BLK=4 * P.VPL,
+        u = 4 if P.ring else 1          # unit of the handler offsets in an op: dwords in the experimental ring kernels
+        L = dict(VPL=P.VPL, RS=P.RS, K=P.K, G=P.G, W=P.W, MAXD=P.MAXD, MAXA=P.MAXA, R=R, NWAIT=P.NWAIT, BLK=4 * P.VPL // u,
                  M0_SRC1=M0_SRC1, code_bytes=o["__end"], nvgpr=P.nvgpr)
-        L["add"] = {key: o[name] - base for key, name in self.lines.items()}
-        L["load"] = [[0] + [o["load_b%d_n%d" % (b, n)] - base for n in range(1, P.W + 1)] for b in range(P.NB)]
+        L["add"] = {key: (o[name] - base) // u for key, name in self.lines.items()}
+        L["load"] = [[0] + [(o["load_b%d_n%d" % (b, n)] - base) // u for n in range(1, P.W + 1)] for b in range(P.NB)]
         L["NB"] = P.NB
-        L["wait"] = [o["wait_%d" % k] - base for k in range(P.NWAIT)]
-        L["refill"] = o["refill"] - base
-        L["end"] = o["end"] - base
-        assert max(L["wait"] + [L["end"], L["refill"]]) < 32768, "op offsets are 16-bit signed"
+        L["wait"] = [(o["wait_%d" % k] - base) // u for k in range(P.NWAIT)]
+        L["ring"] = P.ring
+        if P.ring:
+            L["pf"] = [0] + [(o["pf_n%d" % n] - base) // u for n in range(1, P.W + 1)]
+            L["cp"] = [0] + [(o["cp_n%d" % n] - base) // u for n in range(1, P.W + 1)]
+        L["refill"] = (o["refill"] - base) // u
+        L["end"] = (o["end"] - base) // u
+        assert max(L["wait"] + [L["end"], L["refill"]]) < (65536 if P.ring else 32768), "op offsets are 16 bits"
         return L
 
     def render(self):
@@ -648,12 +898,12 @@ class Gen:
             else:
                 line = i.render()
                 # local labels: branch targets and the code_base difference
-                line = re.sub(r"\b(code_base|after_getpc|done|pf_done|pf_loop\d+|load_b\d+_blk\d+|nodiv_\d+_\d+|nostore_\d+_\d+)\b", lambda m: ".L%s_%s" % (name, m.group(1)), line)
+                line = re.sub(r"\b(code_base|after_getpc|done|pf_done|pf_loop\d+|load_b\d+_blk\d+|nodiv_\d+_\d+|nostore_\d+_\d+|pf_blk\d+|cp_blk\d+|p_div|p_divd|p_z|p_patch|p_nextz|e_nofetch)\b", lambda m: ".L%s_%s" % (name, m.group(1)), line)
                 out.append(line)
-        kargs = 0x80 if P.wta else 0x60
+        kargs = 0x80 if (P.wta or P.persist) else 0x60
         out += [".Lfunc_end_%s:" % name, ".size %s, .Lfunc_end_%s-%s" % (name, name, name), "",
                 ".rodata", ".p2align 6", ".amdhsa_kernel %s" % name,
-                "  .amdhsa_group_segment_fixed_size 0", "  .amdhsa_private_segment_fixed_size 0",
+                "  .amdhsa_group_segment_fixed_size %d" % (P.ring * 256 * P.VPL), "  .amdhsa_private_segment_fixed_size 0",
                 "  .amdhsa_kernarg_size %d" % kargs, "  .amdhsa_user_sgpr_count 2",
                 "  .amdhsa_user_sgpr_kernarg_segment_ptr 1", "  .amdhsa_system_sgpr_workgroup_id_x 1",
                 "  .amdhsa_system_sgpr_workgroup_id_y 1", "  .amdhsa_system_sgpr_workgroup_id_z 1",
@@ -664,7 +914,7 @@ class Gen:
                 "  .amdhsa_ieee_mode 1", ".end_amdhsa_kernel", "",
                 ".amdgpu_metadata", "---", "amdhsa.version:", "  - 1", "  - 2", "amdhsa.kernels:",
                 "  - .name: %s" % name, "    .symbol: %s.kd" % name, "    .kernarg_segment_size: %d" % kargs,
-                "    .kernarg_segment_align: 8", "    .group_segment_fixed_size: 0", "    .private_segment_fixed_size: 0",
+                "    .kernarg_segment_align: 8", "    .group_segment_fixed_size: %d" % (P.ring * 256 * P.VPL), "    .private_segment_fixed_size: 0",
                 "    .wavefront_size: 64", "    .sgpr_count: %d" % (NSGPR + 6), "    .vgpr_count: %d" % P.nvgpr_alloc,
                 "    .agpr_count: 0", "    .max_flat_workgroup_size: 64", "    .args:"]
         off = 0
@@ -710,12 +960,14 @@ def main():
     ap.add_argument("--nb", type=int, default=1)
     ap.add_argument("--pf", type=int, default=0)
     ap.add_argument("--wta", action="store_true")
+    ap.add_argument("--persist", action="store_true", help="experimental (with --ring): persistent waves")
+    ap.add_argument("--ring", type=int, default=0, help="experimental: window rows through an LDS ring of this many slots")
     ap.add_argument("--skip", action="store_true", help="the kernel of the skip programs (unit regions neither divided nor stored)")
     ap.add_argument("--minvgpr", type=int, default=0, help="experiments: allocate at least this many VGPRs (occupancy)")
     ap.add_argument("-o", default=None)
     ap.add_argument("--header", default=None)
     a = ap.parse_args()
-    P = Params(vpl=a.vpl, K=a.k, W=a.w, NB=a.nb, PF=a.pf, wta=a.wta, order=a.order, minvgpr=a.minvgpr, skip=a.skip)
+    P = Params(vpl=a.vpl, K=a.k, W=a.w, NB=a.nb, PF=a.pf, wta=a.wta, order=a.order, minvgpr=a.minvgpr, skip=a.skip, ring=a.ring, persist=a.persist)
     g = Gen(P).build()
     if a.o:
         open(a.o, "w").write(g.render())

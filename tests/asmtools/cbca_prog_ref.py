@@ -193,7 +193,36 @@ def build_program(sup0, H, W, y0, x0, L, skip_unit=False):
                     assert 1 <= n <= MAXA and 0 <= sf and sf + n - 1 < WW
                     emit((L["add"][(j, aset, "a")] + (MAXA - n) * BLK * nk) | ((M0 | (RS * (wb + sf + n - 1))) << 16))
 
-    if NB == 1:
+    if L.get("ring"):
+        # experimental (cbca_prog_gen.py --ring S): the units travel through an LDS ring of S slots.  PF streams a unit into
+        # the next free slots (behind the head; a unit that does not fit there starts at slot 0 - the kernel keeps the
+        # same head), as many units ahead as the ring holds; WAIT k lets the oldest unit arrive (k = slots requested after
+        # it), CP copies it into the register window and frees its slots.
+        S = L["ring"]
+        head, issued, live = 0, 0, []
+
+        def try_issue():
+            nonlocal head, issued
+            while issued < len(units):
+                lo, hi, p, _ = units[issued]
+                n = hi - lo + 1
+                start = 0 if head + n > S else head
+                if any(start < a + m and a < start + n for a, m in live):
+                    break
+                emit(L["pf"][n] | (p << 16))
+                live.append((start, n))
+                head = start + n
+                issued += 1
+        try_issue()
+        for i in range(len(units)):
+            n = units[i][1] - units[i][0] + 1
+            assert live, "unit %d was never requested" % i
+            emit(L["wait"][sum(m for _, m in live[1:])] | (M0 << 16))
+            emit(L["cp"][n] | (M0 << 16))
+            live.pop(0)
+            try_issue()
+            arms(i)
+    elif NB == 1:
         for i in range(len(units)):
             load(i)
             arms(i)

@@ -26,11 +26,15 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 K_DEFAULT = 2
 
 
+RING = 0
+MINVGPR = 0
+
+
 def build_hsaco(vpl, w, outdir, nb=1, debug=0, pf=0, k=None):
     k = k or K_DEFAULT
     os.makedirs(outdir, exist_ok=True)
-    g = gen.Gen(gen.Params(vpl=vpl, K=k, W=w, NB=nb, debug=debug, PF=pf)).build()
-    base = os.path.join(outdir, "cbca_prog_v%d_k%d_w%d_b%d_g%d_p%d" % (vpl, k, w, nb, debug, pf))
+    g = gen.Gen(gen.Params(vpl=vpl, K=k, W=w, NB=nb, debug=debug, PF=pf, ring=RING, minvgpr=MINVGPR)).build()
+    base = os.path.join(outdir, "cbca_prog_v%d_k%d_w%d_b%d_g%d_p%d_r%d_m%d" % (vpl, k, w, nb, debug, pf, RING, MINVGPR))
     if not os.path.exists(base + ".hsaco") or os.path.getmtime(base + ".hsaco") < os.path.getmtime(gen.__file__):
         open(base + ".s", "w").write(g.render())
         subprocess.check_call([LLVM + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c",
@@ -121,12 +125,14 @@ def main():
     ap.add_argument("--nb", type=int, default=1); ap.add_argument("--skip-small", action="store_true")
     ap.add_argument("--experiments", action="store_true"); ap.add_argument("--pf", default="")
     ap.add_argument("--k", type=int, default=2); ap.add_argument("--order", type=int, default=0)
+    ap.add_argument("--ring", type=int, default=0, help="experimental: window rows through an LDS ring of this many slots")
+    ap.add_argument("--minvgpr", type=int, default=0)
     args = ap.parse_args()
-    global K_DEFAULT
-    K_DEFAULT = args.k
+    global K_DEFAULT, RING, MINVGPR
+    K_DEFAULT, RING, MINVGPR = args.k, args.ring, args.minvgpr
     hip.require_device()
     allok = True
-    for vpl in (() if args.skip_small else (4, 2, 3)):
+    for vpl in (() if args.skip_small else (4,) if RING else (4, 2, 3)):   # (no 8-byte buffer_load ... lds on gfx950)
         g, path = build_hsaco(vpl, args.w, os.path.join(ROOT, "mc-cnn-python_amd", "build", "asm"), args.nb)
         mod = Module(path, g.P.name())
         L = g.layout()
