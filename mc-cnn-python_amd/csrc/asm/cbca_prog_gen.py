@@ -311,7 +311,6 @@ class Gen:
         e("s_add_u32", s("prg"), s("prg"), s("rg"), comment="patch row group")
         e("v_lshlrev_b32", vreg(P.v_lane4), 2, "v0")
         e("v_lshlrev_b32", vreg(P.v_lane16), 4, "v0")
-        e("v_mov_b32", vreg(P.v_lds), "v0", comment="lane id (v0 becomes an accumulator)")
         e("s_lshl_b32", s("pix"), s("Dp"), 2)
         e("s_getpc_b64", s("base", 2))
         self.label("after_getpc")
@@ -341,7 +340,8 @@ class Gen:
         # voff = d0 * 4 with d0 = (chunk * 64 + lane) * VPL, or kDrop past the disparity range
         e("s_lshl_b32", s("t1"), s("chunk"), 6)
         vt = P.PHYS_WIN
-        e("v_add_u32", vreg(vt), s("t1"), vreg(P.v_lds))
+        e("v_lshrrev_b32", vreg(vt), 2, vreg(P.v_lane4), comment="lane id")
+        e("v_add_u32", vreg(vt), s("t1"), vreg(vt))
         e("v_mul_u32_u24", vreg(vt), 4 * VPL, vreg(vt))
         e("v_mov_b32", vreg(P.v_voff), KDROP)
         e("v_cmp_gt_u32", "vcc", s("pix"), vreg(vt))

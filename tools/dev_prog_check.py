@@ -28,13 +28,14 @@ K_DEFAULT = 2
 
 RING = 0
 MINVGPR = 0
+PERSIST = False
 
 
 def build_hsaco(vpl, w, outdir, nb=1, debug=0, pf=0, k=None):
     k = k or K_DEFAULT
     os.makedirs(outdir, exist_ok=True)
-    g = gen.Gen(gen.Params(vpl=vpl, K=k, W=w, NB=nb, debug=debug, PF=pf, ring=RING, minvgpr=MINVGPR)).build()
-    base = os.path.join(outdir, "cbca_prog_v%d_k%d_w%d_b%d_g%d_p%d_r%d_m%d" % (vpl, k, w, nb, debug, pf, RING, MINVGPR))
+    g = gen.Gen(gen.Params(vpl=vpl, K=k, W=w, NB=nb, debug=debug, PF=pf, ring=RING, minvgpr=MINVGPR, persist=PERSIST)).build()
+    base = os.path.join(outdir, "cbca_prog_v%d_k%d_w%d_b%d_g%d_p%d_r%d_m%d_s%d" % (vpl, k, w, nb, debug, pf, RING, MINVGPR, int(PERSIST)))
     if not os.path.exists(base + ".hsaco") or os.path.getmtime(base + ".hsaco") < os.path.getmtime(gen.__file__):
         open(base + ".s", "w").write(g.render())
         subprocess.check_call([LLVM + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c",
@@ -63,8 +64,22 @@ class Module:
         assert rc == 0, "hipModuleLaunchKernel -> %d" % rc
 
 
+def grid_of(meta, nz):
+    """The launch grid: one wave per patch and (image, chunk), or (persistent kernels) 8 x NWC x band_groups waves."""
+    if not PERSIST:
+        return (8 * meta["band_groups"], meta["ngroups"], nz)
+    return (8 * nwc_of(meta) * meta["band_groups"], 1, 1)
+
+
+def nwc_of(meta):
+    per_cu = max(1, min(12, 160 // max(RING, 1)))          # waves a CU holds: LDS-limited
+    return max(1, (32 * per_cu) // meta["band_groups"])
+
+
 def kargs(ins, outs, progs, sups, Dp, H, W, nchunks, meta):
-    k = np.zeros(0x60 // 4, np.uint32)
+    k = np.zeros((0x80 if PERSIST else 0x60) // 4, np.uint32)
+    if PERSIST:
+        k[24] = nwc_of(meta)
     for i, t in enumerate(ins + outs + progs + sups):
         a = t.data_ptr()
         k[2 * i], k[2 * i + 1] = a & 0xffffffff, a >> 32
@@ -105,8 +120,7 @@ def check_shape(mod, g, L, H, W, D, seed, flat=False):
     progs, meta = programs_for(sup, H, W, L)
     out = torch.full_like(a, float("nan"))
     nchunks = -(-Dp // (64 * P.VPL))
-    mod.launch((8 * meta["band_groups"], meta["ngroups"], nchunks),
-               kargs([a, a], [out, out], [progs, progs], [sup, sup], Dp, H, W, nchunks, meta))
+    mod.launch(grid_of(meta, nchunks), kargs([a, a], [out, out], [progs, progs], [sup, sup], Dp, H, W, nchunks, meta))
     torch.cuda.synchronize()
     ok = torch.equal(out[:, :, :D].nan_to_num(777.), want[:, :, :D].nan_to_num(777.))
     print("shape %dx%dx%d seed %d flat %d: %s  (longest program %d of %d)" % (H, W, D, seed, flat, ok, meta["longest"],
@@ -126,10 +140,10 @@ def main():
     ap.add_argument("--experiments", action="store_true"); ap.add_argument("--pf", default="")
     ap.add_argument("--k", type=int, default=2); ap.add_argument("--order", type=int, default=0)
     ap.add_argument("--ring", type=int, default=0, help="experimental: window rows through an LDS ring of this many slots")
-    ap.add_argument("--minvgpr", type=int, default=0)
+    ap.add_argument("--minvgpr", type=int, default=0); ap.add_argument("--persist", action="store_true")
     args = ap.parse_args()
-    global K_DEFAULT, RING, MINVGPR
-    K_DEFAULT, RING, MINVGPR = args.k, args.ring, args.minvgpr
+    global K_DEFAULT, RING, MINVGPR, PERSIST
+    K_DEFAULT, RING, MINVGPR, PERSIST = args.k, args.ring, args.minvgpr, args.persist
     hip.require_device()
     allok = True
     for vpl in (() if args.skip_small else (4,) if RING else (4, 2, 3)):   # (no 8-byte buffer_load ... lds on gfx950)
@@ -170,11 +184,11 @@ def main():
     want_r = want_r.clone()
     ka = kargs([a, c], [b, d], [pl, pr], [sl, sr], Dp, H, W, nchunks, meta)
     b.fill_(float("nan")); d.fill_(float("nan"))
-    mod.launch((8 * meta["band_groups"], meta["ngroups"], nchunks * 2), ka)
+    mod.launch(grid_of(meta, nchunks * 2), ka)
     torch.cuda.synchronize()
     print("full size bit-exact vs cbca_hwd: left %s right %s" % (torch.equal(b, want_l), torch.equal(d, want_r)), flush=True)
     vb = 4.0 * H * W * D
-    ms = timeit(lambda: mod.launch((8 * meta["band_groups"], meta["ngroups"], nchunks * 2), ka), args.iters)
+    ms = timeit(lambda: mod.launch(grid_of(meta, nchunks * 2), ka), args.iters)
     print("K=%d W=%d NB=%d regs=%d" % (g.P.K, args.w, args.nb, g.P.nvgpr))
     print("cbca_prog pair      %8.4f ms  %6.1f GB/s (%.1f%% of 8 TB/s)" % (ms, 4 * vb / ms / 1e6, 4 * vb / ms / 1e6 / 80), flush=True)
     for pf in [int(x) for x in args.pf.split(",") if x]:
