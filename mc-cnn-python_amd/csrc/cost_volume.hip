@@ -123,6 +123,158 @@ __global__ __launch_bounds__(256) void cost_volume_exact_kernel(const float *__r
     }
 }
 
+// ---- bit-exact products for the pixel-major volumes, two scores per LDS row (round 4) ---------------------------------
+// cost_volume_exact_kernel<true> is bound by its LDS reads: every score fetches the 64 right-image features of its own
+// (w, d) - 256 bytes - out of LDS.  But S(w, d + 1) needs the row of right pixel w - d - 1, which is exactly the row
+// lane w - 1 has just fetched for S(w - 1, d): here every lane fetches ONE row per pair of disparities and multiplies
+// it twice - with its own left features for d, and, read across the lane boundary by the DPP operand modifier
+// (wave_shr:1: lane l reads lane l - 1's register, no extra instruction), for d + 1.  Half the LDS bytes per score; the
+// arithmetic and its order per score are unchanged (NumPy's float32 pairwise sum of the 64 rounded products, pf:87-91):
+// bit-identical.  Lane 0 has no left neighbour: it is a ghost lane that carries the pixel in front of the tile (the
+// last pixel of the tile to the left, which computes that pixel's scores itself), so a tile is 63 pixels wide.  The
+// compute is unconditional - a lane's rows must exist for its neighbour - and only the hand-over to the score tile is
+// predicated.
+constexpr int CVP_TW = 63;   // new pixels per tile (lanes 1 .. 63)
+#ifndef CVP_ABL
+#define CVP_ABL 0            // timing-only ablations (wrong results): 1 no products, 2 no volume stores
+#endif
+__global__ __launch_bounds__(256, 3) void cost_volume_exact_pairs_kernel(const float *__restrict__ fl,
+                                                                         const float *__restrict__ fr, int H, int W, int D,
+                                                                         float *__restrict__ lcv, float *__restrict__ rcv,
+                                                                         int Dp)
+{
+    // A workgroup owns 63 new pixels of one image row and walks ALL their disparity tiles: the left features stay in
+    // registers, and the right-image rows live in a ring of 128 LDS rows indexed by (column & 127) - a tile of 64
+    // disparities needs the 127 columns w0 - d0 - 63 .. w0 - d0 + 63, of which the next tile reuses 63: only 64 new
+    // rows are fetched per tile (into registers before the tile's products, into the ring behind them).
+    constexpr int RING = 128;
+    __shared__ __attribute__((aligned(16))) float sR[RING * CV_LD];
+    __shared__ __attribute__((aligned(16))) float sL[CV_TW * CV_LD];
+    const int w0 = (int)blockIdx.x * CVP_TW - 1, h = blockIdx.y;   // lane 0: pixel w0 (ghost)
+    const int tid = threadIdx.x;
+    const size_t rowbase = (size_t)h * W;
+    for (int i = tid; i < CV_TW * 16; i += 256) {
+        const int px = i >> 4, c4 = i & 15;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (w0 + px >= 0 && w0 + px < W) v = *reinterpret_cast<const float4 *>(fl + (rowbase + w0 + px) * CV_C + c4 * 4);
+        *reinterpret_cast<float4 *>(&sL[px * CV_LD + c4 * 4]) = v;
+    }
+    // the first tile's columns w0 - 63 .. w0 + 63
+    for (int i = tid; i < (CV_TW + CV_DT - 1) * 16; i += 256) {
+        const int x = w0 - (CV_DT - 1) + (i >> 4), c4 = i & 15;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (x >= 0 && x < W) v = *reinterpret_cast<const float4 *>(fr + (rowbase + x) * CV_C + c4 * 4);
+        *reinterpret_cast<float4 *>(&sR[(x & (RING - 1)) * CV_LD + c4 * 4]) = v;
+    }
+    __syncthreads();
+
+    const int wl = tid & 63, dq = tid >> 6;  // dq is wave-uniform: each wave owns 16 disparities = 8 pairs of a tile
+    const int w = w0 + wl;
+    float a[CV_C];
+#pragma unroll
+    for (int c4 = 0; c4 < 16; ++c4) {
+        const float4 v = *reinterpret_cast<const float4 *>(&sL[wl * CV_LD + c4 * 4]);
+        a[c4 * 4 + 0] = v.x; a[c4 * 4 + 1] = v.y; a[c4 * 4 + 2] = v.z; a[c4 * 4 + 3] = v.w;
+    }
+    constexpr int TP = 65;              // pitch of the score tile
+    float *const sT = sL;               // every thread holds its left features in registers from here on
+    __syncthreads();
+    const int dl = tid & 63;
+#pragma unroll 1
+    for (int d0 = 0; d0 < D && w0 + CV_TW - 1 >= d0; d0 += CV_DT) {   // beyond: every (w, d) has w < d (border fill)
+        // the next tile's 64 new columns w0 - d0 - 127 .. w0 - d0 - 64 on their way (4 x 16 bytes per thread)
+        const bool more = d0 + CV_DT < D && w0 + CV_TW - 1 >= d0 + CV_DT;
+        float4 nx[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + q * 256, x = w0 - d0 - (2 * CV_DT - 1) + (i >> 4), c4 = i & 15;
+            nx[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (more && x >= 0 && x < W) nx[q] = *reinterpret_cast<const float4 *>(fr + (rowbase + x) * CV_C + c4 * 4);
+        }
+#pragma unroll 1
+        for (int kk = 0; kk < ((CVP_ABL & 1) ? (D == 12345 ? 8 : 0) : 8); ++kk) {
+            const int dloc = dq * 16 + 2 * kk;                   // the even disparity of the pair (tile-relative)
+            const int r = (w - d0 - dloc) & (RING - 1);          // ring row of right column w - d_even
+            const float *b = &sR[r * CV_LD];
+            float acc[8], acn[8];                                // this lane's score for d_even; for d_even + 1 (neighbour's row)
+            // numpy pairwise_sum, n = 64: r[j] = p[j]; r[j] += p[8i+j]; ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))
+            // eight channels at a time, the next eight fetched under them
+            float4 n0 = *reinterpret_cast<const float4 *>(b), n1 = *reinterpret_cast<const float4 *>(b + 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float bv[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+                if (i < 7) {
+                    n0 = *reinterpret_cast<const float4 *>(b + (i + 1) * 8);
+                    n1 = *reinterpret_cast<const float4 *>(b + (i + 1) * 8 + 4);
+                }
+                // the float32 operations of four channels as one block of instructions, independent ones next to each
+                // other (the compiler otherwise defers one half of them to the end of the row and keeps - or spills -
+                // everything they need until then)
+#pragma unroll
+                for (int j = 0; j < 8; j += 4) {
+                    if (i == 0) {
+                        asm volatile("v_mul_f32 %0, %8, %12\n\tv_mul_f32 %1, %9, %13\n\tv_mul_f32 %2, %10, %14\n\tv_mul_f32 %3, %11, %15\n\t"
+                                     "v_mul_f32_dpp %4, %12, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                                     "v_mul_f32_dpp %5, %13, %9 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                                     "v_mul_f32_dpp %6, %14, %10 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                                     "v_mul_f32_dpp %7, %15, %11 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                                     : "=&v"(acc[j]), "=&v"(acc[j + 1]), "=&v"(acc[j + 2]), "=&v"(acc[j + 3]),
+                                       "=&v"(acn[j]), "=&v"(acn[j + 1]), "=&v"(acn[j + 2]), "=&v"(acn[j + 3])
+                                     : "v"(a[j]), "v"(a[j + 1]), "v"(a[j + 2]), "v"(a[j + 3]),
+                                       "v"(bv[j]), "v"(bv[j + 1]), "v"(bv[j + 2]), "v"(bv[j + 3]));
+                    } else {
+                        float t0, t1, t2, t3;
+                        asm volatile("v_mul_f32 %8, %12, %16\n\tv_mul_f32 %9, %13, %17\n\tv_mul_f32 %10, %14, %18\n\tv_mul_f32 %11, %15, %19\n\t"
+                                     "v_add_f32 %0, %0, %8\n\tv_add_f32 %1, %1, %9\n\tv_add_f32 %2, %2, %10\n\tv_add_f32 %3, %3, %11\n\t"
+                                     "v_mul_f32_dpp %8, %16, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                                     "v_mul_f32_dpp %9, %17, %13 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                                     "v_mul_f32_dpp %10, %18, %14 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                                     "v_mul_f32_dpp %11, %19, %15 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                                     "v_add_f32 %4, %4, %8\n\tv_add_f32 %5, %5, %9\n\tv_add_f32 %6, %6, %10\n\tv_add_f32 %7, %7, %11"
+                                     : "+v"(acc[j]), "+v"(acc[j + 1]), "+v"(acc[j + 2]), "+v"(acc[j + 3]),
+                                       "+v"(acn[j]), "+v"(acn[j + 1]), "+v"(acn[j + 2]), "+v"(acn[j + 3]),
+                                       "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                                     : "v"(a[i * 8 + j]), "v"(a[i * 8 + j + 1]), "v"(a[i * 8 + j + 2]), "v"(a[i * 8 + j + 3]),
+                                       "v"(bv[j]), "v"(bv[j + 1]), "v"(bv[j + 2]), "v"(bv[j + 3]));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+            float sn = ((acn[0] + acn[1]) + (acn[2] + acn[3])) + ((acn[4] + acn[5]) + (acn[6] + acn[7]));
+            s = 0.f + s;  // np.sum adds the pairwise result to the identity
+            sn = 0.f + sn;
+            s = -1.f * s;
+            sn = -1.f * sn;
+            const int d = d0 + dloc;
+            if (wl >= 1 && w < W) {
+                if (d < D && w >= d) sT[wl * TP + dloc] = s;
+                if (d + 1 < D && w >= d + 1) sT[wl * TP + dloc + 1] = sn;
+            }
+        }
+        __syncthreads();                             // products done: the score tile is complete, the oldest ring rows are free
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + q * 256, x = w0 - d0 - (2 * CV_DT - 1) + (i >> 4), c4 = i & 15;
+            if (more) *reinterpret_cast<float4 *>(&sR[(x & (RING - 1)) * CV_LD + c4 * 4]) = nx[q];
+        }
+        const int nd = (CVP_ABL & 2) ? (D == 12345 ? 1 : 0) : min(CV_DT, D - d0);           // disparities of this tile that exist
+        const int xr0 = w0 - d0 - (CV_DT - 1);
+        // left volume: pixel w0 + px (px >= 1), disparities d0 .. d0 + nd - 1 (those with d <= w), 64 lanes = 64 disparities
+        for (int px = 1 + (tid >> 6); px < CV_TW; px += 4) {
+            const int ww = w0 + px, d = d0 + dl;
+            if (ww < W && dl < nd && ww >= d) lcv[(rowbase + ww) * (size_t)Dp + d] = sT[px * TP + dl];
+        }
+        // right volume: pixel x = w - d; its entries of this tile are (w = x + d, d), d0 <= d < d0 + nd
+        for (int xi = tid >> 6; xi < CV_TW + CV_DT - 1; xi += 4) {
+            const int x = xr0 + xi, d = d0 + dl, px = x + d - w0;      // tile row of w = x + d
+            if (x >= 0 && dl < nd && px >= 1 && px < CV_TW && w0 + px < W)
+                rcv[(rowbase + x) * (size_t)Dp + d] = sT[px * TP + dl];
+        }
+        __syncthreads();                             // the score tile has been read, the ring holds the next tile's rows
+    }
+}
+
 // ---- MFMA variant ---------------------------------------------------------------------------------------------
 // One wave computes a 32(w) x 32(w') block of S = <fl[w], fr[w']>; a workgroup of 4 waves covers 64 w x 64 w' and
 // keeps only the band 0 <= w-w' < D.  A/B operands: lane l holds pixel l&31, channels 8 (l>>5) .. +7 of a 16-channel
@@ -524,8 +676,13 @@ extern "C" int mccnn_cost_volume_hwd(const float *fl, const float *fr, int H, in
     MCCNN_REQUIRE((size_t)W * Dp * 4 < ((size_t)1 << 31), MCCNN_E_UNSUPPORTED,
                   "mccnn_cost_volume_hwd: a %d x %d row exceeds a buffer descriptor's reach", W, D);
     hipStream_t s = (hipStream_t)stream;
+#ifdef CV_HWD_TILE_KERNEL      // A/B builds: one LDS row per score
     const dim3 grid(cdiv(W, CV_TW), H, cdiv(D, CV_DT));
     hipLaunchKernelGGL(cost_volume_exact_kernel<true>, grid, dim3(256), 0, s, fl, fr, H, W, D, lcv_hwd, rcv_hwd, Dp);
+#else
+    const dim3 grid(cdiv(W, CVP_TW), H, 1);
+    hipLaunchKernelGGL(cost_volume_exact_pairs_kernel, grid, dim3(256), 0, s, fl, fr, H, W, D, lcv_hwd, rcv_hwd, Dp);
+#endif
     int rc = check_launch("mccnn_cost_volume_hwd");
     if (rc) return rc;
     if (D > 1) {
