@@ -138,6 +138,8 @@ constexpr int CVP_TW = 63;   // new pixels per tile (lanes 1 .. 63)
 #ifndef CVP_ABL
 #define CVP_ABL 0            // timing-only ablations (wrong results): 1 no products, 2 no volume stores
 #endif
+// (an ablated part stays in the code, behind a condition no real call meets, so that registers and LDS do not change)
+__device__ __forceinline__ bool cvp_never(int D) { return D == 12345; }
 __global__ __launch_bounds__(256, 3) void cost_volume_exact_pairs_kernel(const float *__restrict__ fl,
                                                                          const float *__restrict__ fr, int H, int W, int D,
                                                                          float *__restrict__ lcv, float *__restrict__ rcv,
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256, 3) void cost_volume_exact_pairs_kernel(const f
             if (more && x >= 0 && x < W) nx[q] = *reinterpret_cast<const float4 *>(fr + (rowbase + x) * CV_C + c4 * 4);
         }
 #pragma unroll 1
-        for (int kk = 0; kk < ((CVP_ABL & 1) ? (D == 12345 ? 8 : 0) : 8); ++kk) {
+        for (int kk = 0; kk < (((CVP_ABL & 1) && !cvp_never(D)) ? 0 : 8); ++kk) {
             const int dloc = dq * 16 + 2 * kk;                   // the even disparity of the pair (tile-relative)
             const int r = (w - d0 - dloc) & (RING - 1);          // ring row of right column w - d_even
             const float *b = &sR[r * CV_LD];
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(256, 3) void cost_volume_exact_pairs_kernel(const f
             const int i = tid + q * 256, x = w0 - d0 - (2 * CV_DT - 1) + (i >> 4), c4 = i & 15;
             if (more) *reinterpret_cast<float4 *>(&sR[(x & (RING - 1)) * CV_LD + c4 * 4]) = nx[q];
         }
-        const int nd = (CVP_ABL & 2) ? (D == 12345 ? 1 : 0) : min(CV_DT, D - d0);           // disparities of this tile that exist
+        const int nd = ((CVP_ABL & 2) && !cvp_never(D)) ? 0 : min(CV_DT, D - d0);   // disparities of this tile that exist
         const int xr0 = w0 - d0 - (CV_DT - 1);
         // left volume: pixel w0 + px (px >= 1), disparities d0 .. d0 + nd - 1 (those with d <= w), 64 lanes = 64 disparities
         for (int px = 1 + (tid >> 6); px < CV_TW; px += 4) {
