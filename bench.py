@@ -44,8 +44,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--fast", action="store_true",
-                    help="the tolerance-checked variants (split-f16 MFMA features + cost volume, separable float64-prefix "
-                         "CBCA) instead of the bit-exact float32 default")
+                    help="the tolerance-checked variant: the cost volume on the matrix cores (split-f16 operands, <= 2e-6) in "
+                         "front of the bit-exact stages, instead of the bit-exact float32 default")
+    ap.add_argument("--separable-cbca", action="store_true",
+                    help="with --fast: also the separable float64-prefix aggregation on plane-major volumes (the fast "
+                         "variants of rounds 2-3; slower than the default since round 4)")
     ap.add_argument("--exact", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--split-features", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--library-features", action="store_true",
@@ -65,6 +68,8 @@ def parse():
     a = ap.parse_args()
     if a.fast and a.exact:
         ap.error("--fast and --exact exclude each other")
+    if a.separable_cbca and not a.fast:
+        ap.error("--separable-cbca belongs to --fast")
     a.exact = not a.fast
     return a
 
@@ -201,7 +206,7 @@ def main():
     lib_features = args.library_features
     matcher = sd.StereoMatcher(
         net, cv_mode=hip.MCCNN_CV_EXACT if args.exact else hip.MCCNN_CV_MFMA,
-        cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER if args.exact else hip.MCCNN_CBCA_SEPARABLE,
+        cbca_order=hip.MCCNN_CBCA_SEPARABLE if args.separable_cbca else hip.MCCNN_CBCA_REFERENCE_ORDER,
         features="miopen" if lib_features else "split_f16")
 
     use_graph = not args.no_graph
@@ -315,7 +320,7 @@ def main():
         # the other variant on the same box and pair, outside `value` (10 pairs, graph replay): the fast variants when
         # the default was benchmarked (with their distance to it), the default when a fast variant was
         if is_default:
-            other = sd.StereoMatcher(net, cv_mode=hip.MCCNN_CV_MFMA, cbca_order=hip.MCCNN_CBCA_SEPARABLE,
+            other = sd.StereoMatcher(net, cv_mode=hip.MCCNN_CV_MFMA, cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER,
                                      features="split_f16")
             keep_o = {}
             out_o = other.match(dl, dr, D, keep=keep_o)
@@ -430,9 +435,11 @@ def main():
                    "variant": "bit-exact (float32; every stage after the conv features bit-identical to the reference's "
                               "NumPy on the same features; the features within 3e-7 of a float64 evaluation of the network)"
                    if args.exact else
-                   "fast (split-f16 MFMA cost volume, separable float64-prefix CBCA); stated tolerance against the "
+                   "fast (split-f16 MFMA cost volume%s); stated tolerance against the "
                    "bit-exact variant (src/tolerances.py, asserted on `parity` below): WTA flips <= 1e-4 of the pixels per "
-                   "view, >= 98 % of the final map within 1e-3 px, 99th percentile <= 0.02 px",
+                   "view, >= 98 %% of the final map within 1e-3 px, 99th percentile <= 0.02 px"
+                   % (", separable float64-prefix CBCA on plane-major volumes" if args.separable_cbca
+                      else " in front of the bit-exact stages"),
                    "features": "float32 library convolutions (MIOpen)" if lib_features else
                    "hand-written matrix-core convolutions (float32 in/out; every operand as two f16 parts, 3 products per "
                    "multiply, float32 accumulation with the cross terms in their own accumulator: 2.6e-7 .. 3.1e-7 from a "

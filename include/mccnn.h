@@ -70,8 +70,8 @@ int mccnn_cost_volume(const float *fl, const float *fr, int H, int W, int C, int
                       mccnn_stream_t stream);
 
 /* The same volumes written pixel-major ("HWD" [H][W][Dp], the layout the bit-exact variant keeps from here to WTA),
- * bit-identical to mccnn_cost_volume(MCCNN_CV_EXACT) followed by mccnn_dhw_to_hwd for d < D (the Dp - D pad entries of
- * a pixel are not written).  MCCNN_CV_EXACT only; D <= 512. */
+ * bit-identical to mccnn_cost_volume(mode) followed by mccnn_dhw_to_hwd for d < D (the Dp - D pad entries of a pixel
+ * are not written), for MCCNN_CV_EXACT and (ABI 5) MCCNN_CV_MFMA alike; D <= 512. */
 int mccnn_cost_volume_hwd(const float *fl, const float *fr, int H, int W, int C, int D, float *lcv_hwd, float *rcv_hwd,
                           int mode, mccnn_stream_t stream);
 

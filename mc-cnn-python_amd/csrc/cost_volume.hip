@@ -317,9 +317,14 @@ __device__ __forceinline__ void cv_split4(const float4 v, cv_h4 &hi, cv_h4 &lo)
     }
 }
 
+// PIXEL_MAJOR (round 4): the product tile goes to LDS as it is, T[w][x], and leaves as whole disparity runs of the
+// pixel-major volumes "HWD" [H][W][Dp] - a left pixel w takes its row of T (d = w - x: 64 consecutive disparities, 256
+// bytes), a right pixel x its column - so that the matrix-core cost volume can feed the pixel-major pipeline without a
+// layout change (mccnn_cost_volume_hwd with MCCNN_CV_MFMA).  Same products, same bits as the plane-major form.
+template <bool PIXEL_MAJOR>
 __global__ __launch_bounds__(256, CVM_WAVES_PER_SIMD) void cost_volume_mfma_kernel(
     const float *__restrict__ fl, const float *__restrict__ fr, int H, int W, int D, float *__restrict__ lcv,
-    float *__restrict__ rcv, int nwt, int nbands, int total)
+    float *__restrict__ rcv, int nwt, int nbands, int total, int Dp)
 {
     // operand tiles (one channel half at a time) and, after the products are done, the folded product tile share one
     // allocation
@@ -394,6 +399,28 @@ __global__ __launch_bounds__(256, CVM_WAVES_PER_SIMD) void cost_volume_mfma_kern
         }
     }
     __syncthreads();   // every wave is done with the operand tiles: their LDS becomes the product tile
+    if (PIXEL_MAJOR) {
+        constexpr int TP = 65;
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+            const int row = wr + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
+            const int col = wc + (lane & 31);
+            sT[row * TP + col] = (acc[rg] + acc2[rg]) * (-1.f / 1048576.f);
+        }
+        __syncthreads();
+        const int dbase = w0 - x0;
+        // left volume: pixel w0 + r takes row r of T: lane = x, d = dbase + r - lane
+        for (int r = wave; r < 64; r += 4) {
+            const int w = w0 + r, d = dbase + r - lane;
+            if (w < W && d >= 0 && d < D && w >= d) lcv[(rowbase + w) * (size_t)Dp + d] = sT[r * TP + lane];
+        }
+        // right volume: pixel x0 + c takes column c of T: lane = w, d = dbase + lane - c
+        for (int c = wave; c < 64; c += 4) {
+            const int x = x0 + c, d = dbase + lane - c;
+            if (x >= 0 && w0 + lane < W && d >= 0 && d < D) rcv[(rowbase + x) * (size_t)Dp + d] = sT[lane * TP + c];
+        }
+        return;
+    }
     // Products go to LDS diagonal-major and folded, already negated: T[(w - x) & 63][w] (w, x local).  A row of T
     // holds diagonal dd = row in its columns row..63 and diagonal row - 64 in its columns 0..row-1; both run along
     // w, which is how both volumes are written (lcv[d][h][w] and rcv[d][h][w - d]).
@@ -648,8 +675,8 @@ extern "C" int mccnn_cost_volume(const float *fl, const float *fr, int H, int W,
         const int nwt = cdiv(W, 64), nbands = cdiv(D + 63, 64) + 1;
         const long total = (long)nwt * nbands * H;
         MCCNN_REQUIRE(total <= 0x7fffffffL, MCCNN_E_UNSUPPORTED, "mccnn_cost_volume: %ld tiles exceed the grid", total);
-        hipLaunchKernelGGL(cost_volume_mfma_kernel, dim3((unsigned)total), block, 0, s, fl, fr, H, W, D, lcv, rcv, nwt,
-                           nbands, (int)total);
+        hipLaunchKernelGGL(cost_volume_mfma_kernel<false>, dim3((unsigned)total), block, 0, s, fl, fr, H, W, D, lcv, rcv, nwt,
+                           nbands, (int)total, 0);
     } else {
         MCCNN_REQUIRE(false, MCCNN_E_INVALID, "mccnn_cost_volume: unknown mode %d", mode);
     }
@@ -670,21 +697,28 @@ extern "C" int mccnn_cost_volume_hwd(const float *fl, const float *fr, int H, in
     MCCNN_REQUIRE(D <= W - 2, MCCNN_E_UNSUPPORTED,
                   "mccnn_cost_volume_hwd: D=%d needs W >= D+2 (the reference's border recurrence pf:106 is degenerate "
                   "beyond that), W=%d", D, W);
-    MCCNN_REQUIRE(mode == MCCNN_CV_EXACT, MCCNN_E_UNSUPPORTED,
-                  "mccnn_cost_volume_hwd: only MCCNN_CV_EXACT writes pixel-major volumes (mode %d: use "
-                  "mccnn_cost_volume + mccnn_dhw_to_hwd)", mode);
+    MCCNN_REQUIRE(mode == MCCNN_CV_EXACT || mode == MCCNN_CV_MFMA, MCCNN_E_INVALID, "mccnn_cost_volume_hwd: unknown mode %d",
+                  mode);
     MCCNN_REQUIRE(D <= 512, MCCNN_E_UNSUPPORTED, "mccnn_cost_volume_hwd: D=%d > 512", D);
     const int Dp = mccnn_hwd_pitch(D);
     MCCNN_REQUIRE((size_t)W * Dp * 4 < ((size_t)1 << 31), MCCNN_E_UNSUPPORTED,
                   "mccnn_cost_volume_hwd: a %d x %d row exceeds a buffer descriptor's reach", W, D);
     hipStream_t s = (hipStream_t)stream;
+    if (mode == MCCNN_CV_MFMA) {
+        const int nwt = cdiv(W, 64), nbands = cdiv(D + 63, 64) + 1;
+        const long total = (long)nwt * nbands * H;
+        MCCNN_REQUIRE(total <= 0x7fffffffL, MCCNN_E_UNSUPPORTED, "mccnn_cost_volume_hwd: %ld tiles exceed the grid", total);
+        hipLaunchKernelGGL(cost_volume_mfma_kernel<true>, dim3((unsigned)total), dim3(256), 0, s, fl, fr, H, W, D, lcv_hwd,
+                           rcv_hwd, nwt, nbands, (int)total, Dp);
+    } else {
 #ifdef CV_HWD_TILE_KERNEL      // A/B builds: one LDS row per score
-    const dim3 grid(cdiv(W, CV_TW), H, cdiv(D, CV_DT));
-    hipLaunchKernelGGL(cost_volume_exact_kernel<true>, grid, dim3(256), 0, s, fl, fr, H, W, D, lcv_hwd, rcv_hwd, Dp);
+        const dim3 grid(cdiv(W, CV_TW), H, cdiv(D, CV_DT));
+        hipLaunchKernelGGL(cost_volume_exact_kernel<true>, grid, dim3(256), 0, s, fl, fr, H, W, D, lcv_hwd, rcv_hwd, Dp);
 #else
-    const dim3 grid(cdiv(W, CVP_TW), H, 1);
-    hipLaunchKernelGGL(cost_volume_exact_pairs_kernel, grid, dim3(256), 0, s, fl, fr, H, W, D, lcv_hwd, rcv_hwd, Dp);
+        const dim3 grid(cdiv(W, CVP_TW), H, 1);
+        hipLaunchKernelGGL(cost_volume_exact_pairs_kernel, grid, dim3(256), 0, s, fl, fr, H, W, D, lcv_hwd, rcv_hwd, Dp);
 #endif
+    }
     int rc = check_launch("mccnn_cost_volume_hwd");
     if (rc) return rc;
     if (D > 1) {

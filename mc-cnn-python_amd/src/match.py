@@ -9,11 +9,10 @@ im1.png + calib.txt beside it, standardises both views, runs the timed region (f
 exactly where the reference does (match.py:99-110, 182-184).
 
 By default every stage after the conv features is bit-identical to the reference's NumPy code on the same inputs.
-Addition: --fast selects the tolerance-bounded variants of the stages that have one (conv features on the matrix
-cores with split f16 operands instead of the float32 library convolutions, ~5e-7 from a float64 evaluation; cost
-volume on the matrix cores instead of NumPy's summation order, <= 2e-6; CBCA through float64 prefix sums instead of
-the reference's list order, <= 1e-6 per iteration) - about 13x faster; near-ties in the WTA can then resolve
-differently.
+Addition: --fast computes the cost volume on the matrix cores instead of in NumPy's summation order (<= 2e-6 per score;
+near-ties in the WTA can then resolve differently) and leaves every other stage as it is - a few per cent faster;
+--fast --separable_cbca adds the aggregation through float64 prefix sums on plane-major volumes (<= 1e-6 per
+iteration), the fast variant of rounds 2-3, which the bit-exact aggregation has overtaken since.
 Multi-GPU: launch one process per GPU with different -g / -s / -e, as the reference intends (match.py:17, 26-28),
 or use `torchrun --nproc-per-node N match.py ...`: rank r then takes the pairs i = r (mod N) of the window.
 """
@@ -63,9 +62,13 @@ parser.add_argument("--blur_sigma", type=float, default=6, help="bilateral filte
 parser.add_argument("--blur_threshold", type=float, default=2, help="bilateral filter: intensity gate")
 # additions of this implementation
 parser.add_argument("--fast", action="store_true",
-                    help="use the tolerance-bounded fast variants (conv features and cost volume on the matrix cores, "
-                         "<= 2e-6; CBCA through float64 prefix sums, <= 1e-6 per iteration) - about 13x faster.  "
-                         "Without it every stage after the conv features is bit-identical to the reference's NumPy code")
+                    help="the cost volume on the matrix cores (split-f16 operands, <= 2e-6 per score) in front of the "
+                         "bit-exact stages: a few per cent faster, final map within the stated tolerance "
+                         "(src/tolerances.py).  Without it every stage after the conv features is bit-identical to the "
+                         "reference's NumPy code")
+parser.add_argument("--separable_cbca", action="store_true",
+                    help="with --fast: also the separable float64-prefix aggregation on plane-major volumes (<= 1e-6 per "
+                         "iteration; the fast variant of rounds 2-3, slower than the default since round 4)")
 parser.add_argument("--exact", action="store_true", help="(default; kept for compatibility) the bit-exact variants")
 parser.add_argument("--features", choices=("library", "split_f16"), default=None,
                     help="conv feature stack: 'split_f16' (default where the network is 3x3 / 64 maps: the hand-written "
@@ -147,7 +150,8 @@ def main(argv=None):
         return sd.StereoMatcher(
             net, hyper_parameters(args),
             cv_mode=hip.MCCNN_CV_MFMA if args.fast else hip.MCCNN_CV_EXACT,
-            cbca_order=hip.MCCNN_CBCA_SEPARABLE if args.fast else hip.MCCNN_CBCA_REFERENCE_ORDER, features=features,
+            cbca_order=hip.MCCNN_CBCA_SEPARABLE if (args.fast and args.separable_cbca) else hip.MCCNN_CBCA_REFERENCE_ORDER,
+            features=features,
             extras=dict(both_view_support=args.paper_support_regions,
                         interpolation_directions=16 if args.paper_interpolation else 4,
                         occlusion_from_left=args.paper_interpolation, numpy1_promotion=args.numpy1_promotion))

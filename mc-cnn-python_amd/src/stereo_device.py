@@ -143,8 +143,8 @@ def cost_volume(fl, fr, ndisp, mode=hip.MCCNN_CV_EXACT, out=None):
     return lcv, rcv
 
 
-def cost_volume_hwd(fl, fr, ndisp, out=None):
-    """cost_volume(mode=MCCNN_CV_EXACT) written straight into pixel-major volumes [H,W,Dp] (mccnn_cost_volume_hwd)."""
+def cost_volume_hwd(fl, fr, ndisp, out=None, mode=hip.MCCNN_CV_EXACT):
+    """cost_volume(mode) written straight into pixel-major volumes [H,W,Dp] (mccnn_cost_volume_hwd)."""
     H, W, C = fl.shape
     dp = hwd_pitch(ndisp)
     if out is None:
@@ -153,7 +153,7 @@ def cost_volume_hwd(fl, fr, ndisp, out=None):
     else:
         lcv, rcv = out
     hip.check(hip.load().mccnn_cost_volume_hwd(hip.ptr(fl), hip.ptr(fr), H, W, C, int(ndisp), hip.ptr(lcv), hip.ptr(rcv),
-                                               hip.MCCNN_CV_EXACT, hip.stream()), "mccnn_cost_volume_hwd")
+                                               int(mode), hip.stream()), "mccnn_cost_volume_hwd")
     return lcv, rcv
 
 
@@ -766,10 +766,10 @@ class StereoMatcher(object):
             side_work(0)
 
         # the bit-exact variant writes its cost volume pixel-major right away (nothing converts layouts after that)
-        direct = self.pixel_major() and self.cv_mode == hip.MCCNN_CV_EXACT and D <= 512
+        direct = self.pixel_major() and D <= 512
         timer.start("cost_volume")
         if direct:
-            lh, rh = cost_volume_hwd(fl, fr, D, out=(as_hwd(b2), as_hwd(b3)))
+            lh, rh = cost_volume_hwd(fl, fr, D, out=(as_hwd(b2), as_hwd(b3)), mode=self.cv_mode)
         else:
             lcv, rcv = cost_volume(fl, fr, D, self.cv_mode, out=(as_dhw(b0), as_dhw(b1)))
         timer.stop()

@@ -122,16 +122,19 @@ def test_bench_with_library_features():
     assert d["parity_violations"] == [] and d["dtype"] == "f32"
 
 
-def test_bench_fast_variant_states_and_meets_its_tolerance():
-    """bench.py --fast: the tolerance-checked variants; the line states src/tolerances.py's limits, measures them on the
-    timed pair and the script would exit non-zero on a violation."""
+@pytest.mark.parametrize("extra,kernels", [([], ("cbca_iter_prog_pair", "cbca_iter_prog_pair_skip")),
+                                           (["--separable-cbca"], ("cbca_iter_pair",))],
+                         ids=["matrix_core_cost_volume", "and_separable_aggregation"])
+def test_bench_fast_variant_states_and_meets_its_tolerance(extra, kernels):
+    """bench.py --fast [--separable-cbca]: the tolerance-checked variants; the line states src/tolerances.py's limits,
+    measures them on the timed pair and the script would exit non-zero on a violation."""
     import json
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--config", "cfg1", "--fast",
-           "--no-cpu-baseline"]
+           "--no-cpu-baseline"] + extra
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     d = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
-    assert d["roofline"]["kernel"] == "cbca_iter_pair" and d["config"]["variant"].startswith("fast")
+    assert d["roofline"]["kernel"] in kernels and d["config"]["variant"].startswith("fast")
     assert "split-f16" in d["dtype"] and d["parity_violations"] == [] and d["exact_variant_ms_per_step"] > 0
     pp = d["parity"]
     assert not tol.fast_violations(pp["pixels"], pp["wta_flips_left"], pp["wta_flips_right"], pp["frac_within_1e-3_px"],

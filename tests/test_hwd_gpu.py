@@ -269,6 +269,12 @@ def test_cost_volume_pixel_major_equals_plane_major(sd, H, W, D):
     lh, rh = sd.cost_volume_hwd(fl, fr, D)
     assert torch.equal(sd.hwd_to_dhw(lh, D), l0), "left volume"
     assert torch.equal(sd.hwd_to_dhw(rh, D), r0), "right volume"
+    # the matrix-core cost volume (fast variants) written pixel-major: the same bits as its plane-major form
+    fl, fr = torch.nn.functional.normalize(fl, dim=-1), torch.nn.functional.normalize(fr, dim=-1)
+    l1, r1 = sd.cost_volume(fl, fr, D, hip.MCCNN_CV_MFMA)
+    lm, rm = sd.cost_volume_hwd(fl, fr, D, mode=hip.MCCNN_CV_MFMA)
+    assert torch.equal(sd.hwd_to_dhw(lm, D), l1), "left volume, matrix cores"
+    assert torch.equal(sd.hwd_to_dhw(rm, D), r1), "right volume, matrix cores"
 
 
 def test_cost_volume_pixel_major_abi_errors(sd):
@@ -277,8 +283,8 @@ def test_cost_volume_pixel_major_abi_errors(sd):
     f = torch.zeros((4, 40, 64), device="cuda")
     o = torch.zeros((4, 40, 8), device="cuda")
     st = hip.stream()
-    assert lib.mccnn_cost_volume_hwd(hip.ptr(f), hip.ptr(f), 4, 40, 64, 8, hip.ptr(o), hip.ptr(o), hip.MCCNN_CV_MFMA, st) \
-        == hip.MCCNN_E_UNSUPPORTED
+    assert lib.mccnn_cost_volume_hwd(hip.ptr(f), hip.ptr(f), 4, 40, 64, 8, hip.ptr(o), hip.ptr(o), 7, st) \
+        == hip.MCCNN_E_INVALID
     assert lib.mccnn_cost_volume_hwd(hip.ptr(f), hip.ptr(f), 4, 40, 64, 39, hip.ptr(o), hip.ptr(o), hip.MCCNN_CV_EXACT, st) \
         == hip.MCCNN_E_UNSUPPORTED
     assert lib.mccnn_cost_volume_hwd(None, hip.ptr(f), 4, 40, 64, 8, hip.ptr(o), hip.ptr(o), hip.MCCNN_CV_EXACT, st) \

@@ -664,7 +664,7 @@ def test_graph_replay_equals_kernel_by_kernel(sd, net_layers):
     H, W, D = 64, 96, 24
     net = NET(None, input_patch_size=11, batch_size=1, device="cuda").set_layers(net_layers)
     for cv, order, feat in ((hip.MCCNN_CV_MFMA, hip.MCCNN_CBCA_SEPARABLE, "miopen"),
-                            (hip.MCCNN_CV_MFMA, hip.MCCNN_CBCA_SEPARABLE, "split_f16"),      # what bench.py / --fast time
+                            (hip.MCCNN_CV_MFMA, hip.MCCNN_CBCA_SEPARABLE, "split_f16"),      # what bench.py --fast --separable-cbca times
                             (hip.MCCNN_CV_EXACT, hip.MCCNN_CBCA_REFERENCE_ORDER, "miopen")):  # pixel-major pipeline
         m = sd.StereoMatcher(net, cv_mode=cv, cbca_order=order, features=feat)
         for seed in (1, 2, 3):

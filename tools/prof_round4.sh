@@ -17,6 +17,7 @@ if [ "$PART" = 1 ]; then
 else
   timeout 400 python bench.py > $O/r4_bench.json 2> $O/r4_bench.err
   timeout 300 python bench.py --fast --no-cpu-baseline > $O/r4_bench_fast.json 2> $O/r4_bench_fast.err
+  timeout 300 python bench.py --fast --separable-cbca --no-cpu-baseline > $O/r4_bench_fast_separable.json 2> $O/r4_bench_fast_separable.err
   timeout 300 python bench.py --library-features --no-cpu-baseline > $O/r4_bench_library_features.json 2> $O/r4_bench_library_features.err
   for c in cfg1 cfg3 cfg4; do
     timeout 400 python bench.py --config $c --no-cpu-baseline > $O/r4_bench_$c.json 2> $O/r4_bench_$c.err
