@@ -629,8 +629,13 @@ __global__ __launch_bounds__(64) void cost_volume_fill_hwd_lanes_kernel(float *_
     const int voff = d < Dp ? d * 4 : kDrop;
     float x1 = 0.f, x2 = 0.f, x3 = 0.f;
     float buf[PF];
+    // a column is fetched only while some lane of the wave still takes its score from it (columns >= the wave's smallest
+    // disparity on the left side, < W - that disparity on the right): behind that the sweep is pure recurrence
+    const int dmin = (int)blockIdx.z * 64;
     auto issue = [&](int slot, int t) {
-        buf[slot] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, (unsigned)col(min(t, nsteps - 1)) * pix, 0));
+        const int c = col(min(t, nsteps - 1));
+        if (left ? c >= dmin : c < W - dmin)       // wave-uniform
+            buf[slot] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, (unsigned)c * pix, 0));
     };
 #pragma unroll
     for (int k = 0; k < PF; ++k) issue(k, k);
