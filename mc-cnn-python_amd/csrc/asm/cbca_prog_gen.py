@@ -119,8 +119,13 @@ def ins_size(i):
 
 
 class Params:
-    def __init__(self, vpl=4, K=2, G=5, W=12, NB=1, PF=0, wta=False, debug=0, order=0, minvgpr=0, skip=False, ring=0, persist=False):
+    def __init__(self, vpl=4, K=2, G=5, W=12, NB=1, PF=0, wta=False, debug=0, order=0, minvgpr=0, skip=False, ring=0, persist=False,
+                 pipe=0, ntload=False):
         assert K in (1, 2, 4, 8), "anchor sets are aligned power-of-two groups of anchor rows"
+        # ntload: a second LOAD line (n <= G) whose loads carry the non-temporal hint: for region rows that consist of
+        # unit-region pixels only (nobody else's region holds them, so keeping them in L2 only evicts lines that
+        # neighbouring patches will read again)
+        self.ntload = ntload
         assert K * G <= 20, "the region sizes of the K x G anchors live in s[16:35]"
         self.VPL, self.K, self.G, self.W, self.NB, self.PF, self.wta, self.debug = vpl, K, G, W, NB, PF, wta, debug
         self.order = order                          # 0: column-group-major dispatch inside an XCD's band, 1: row-group-major
@@ -129,13 +134,23 @@ class Params:
         # the output buffer: the caller's promise, include/mccnn.h)
         self.skip = skip
         assert not (skip and wta), "the last iteration needs every pixel's values for the WTA: it runs the full programs"
-        self.MAXD = min(W, R + 1)                   # longest descending run one op can carry (self + left arm)
-        self.MAXA = min(W, R)                       # longest ascending run
+        # pipe (round 5): the window is a ring of W slots that the PROGRAM manages.  A LOAD op names its slots (entry
+        # block = highest slot, count, byte offset of the last pixel in the op's second word) and does not wait; the
+        # builder issues the loads of as many upcoming units as the ring holds and puts a WAIT k (k = slots requested
+        # after the unit that is due) in front of each unit's arms: several region rows in flight per wave, the memory
+        # round trips of narrow rows overlap instead of following one another.  `pipe` = the widest unit the builder may
+        # plan (a unit wider than about half the ring would serialise the pipeline again).
+        self.pipe = pipe
+        assert not pipe or (NB == 1 and not ring and not PF and pipe <= W), "pipe: one ring of W slots"
+        self.UW = pipe if pipe else W               # widest window one unit may ask for
+        self.MAXD = min(self.UW, R + 1)             # longest descending run one op can carry (self + left arm)
+        self.MAXA = min(self.UW, R)                 # longest ascending run
         self.RS = vpl + (vpl & 1)                   # registers per slot / accumulator: gfx950 wants even-aligned tuples
         self.nacc = K * G * self.RS
-        # VGPR map: accumulators, four service registers, window
+        # VGPR map: accumulators, four service registers (six with the ops' second words), window
         self.v_voff, self.v_progA, self.v_progB, self.v_lane4 = self.nacc, self.nacc + 1, self.nacc + 2, self.nacc + 3
-        self.PHYS_WIN = max(self.nacc + 4, self.RS * (self.MAXA - 1))
+        self.v_auxA, self.v_auxB = self.nacc + 4, self.nacc + 5
+        self.PHYS_WIN = max(self.nacc + (6 if pipe else 4), self.RS * (self.MAXA - 1))
         self.PHYS_WIN = (self.PHYS_WIN + 3) & ~3
         self.nvgpr = self.PHYS_WIN + NB * W * self.RS      # NB windows: the next one loads under the current one's adds
         self.nvgpr_alloc = max(self.nvgpr, minvgpr)        # experiments: a larger allocation = fewer waves per SIMD
@@ -170,7 +185,7 @@ class Params:
         return out
 
     def name(self):
-        return "mccnn_cbca_prog_v%d%s" % (self.VPL, "_wta" if self.wta else "_skip" if self.skip else "")
+        return "mccnn_cbca_prog_v%d%s%s" % (self.VPL, "p" if self.pipe else "", "_wta" if self.wta else "_skip" if self.skip else "")
 
 
 # ---- scalar register map ------------------------------------------------------------------------------------------
@@ -473,9 +488,16 @@ class Gen:
         e("s_mov_b32", sreg(S["rs_prog"] + 2), s("prog_stride"))
         e("s_mov_b32", sreg(S["rs_prog"] + 3), 0x00020000)
         e("v_lshlrev_b32", vreg(P.v_lane4), 2, "v0", comment="lane * 4 (v0 becomes an accumulator)")
-        e("buffer_load_dword", vreg(P.v_progA), vreg(P.v_lane4), s("rs_prog", 4), 0, offen=True)
-        e("buffer_load_dword", vreg(P.v_progB), vreg(P.v_lane4), s("rs_prog", 4), 0, offen=True, offset=256)
-        e("s_movk_i32", s("progoff"), 512)
+        if P.pipe:        # a 64-op chunk is 512 bytes: the ops, then their second words
+            e("buffer_load_dword", vreg(P.v_progA), vreg(P.v_lane4), s("rs_prog", 4), 0, offen=True)
+            e("buffer_load_dword", vreg(P.v_auxA), vreg(P.v_lane4), s("rs_prog", 4), 0, offen=True, offset=256)
+            e("buffer_load_dword", vreg(P.v_progB), vreg(P.v_lane4), s("rs_prog", 4), 0, offen=True, offset=512)
+            e("buffer_load_dword", vreg(P.v_auxB), vreg(P.v_lane4), s("rs_prog", 4), 0, offen=True, offset=768)
+            e("s_movk_i32", s("progoff"), 1024)
+        else:
+            e("buffer_load_dword", vreg(P.v_progA), vreg(P.v_lane4), s("rs_prog", 4), 0, offen=True)
+            e("buffer_load_dword", vreg(P.v_progB), vreg(P.v_lane4), s("rs_prog", 4), 0, offen=True, offset=256)
+            e("s_movk_i32", s("progoff"), 512)
         if P.ring:
             e("v_lshlrev_b32", vreg(P.v_lane16), 4, "v0", comment="lane * 16: this lane's bytes of an LDS slot")
             e("s_mov_b32", s("ring_head"), 0)
@@ -567,7 +589,27 @@ class Gen:
         # ---- LOAD: entry per (window, n) (parameter -> soffset), then the straight line of loads -----------------------
         # one window: the handler ends with s_waitcnt vmcnt(0) behind the next op's decode; two windows: no wait here,
         # the program says WAIT k (k = loads of the window that was requested last)
-        for b in range(P.NB):
+        if P.pipe:
+            # LOAD k: count - 1 in the parameter, byte offset of the LAST pixel (from the patch's first region row) in the
+            # op's second word -> slots k, k - 1, .. (pixels in descending order, like the plain kernel's line); no wait
+            for k in range(W):                                          # (the last stub falls into its block)
+                self.label("loadk_%d" % k)
+                e("s_sub_u32", s("t0"), s("i"), 1, comment="(i already points at the next op)")
+                e("v_readlane_b32", s("so"), vreg(P.v_auxA), s("t0"))
+                e("s_and_b32", s("t1"), "m0", 0xff)
+                e("s_mov_b32", "m0", s("safe_m0"))
+                if k != W - 1:
+                    e("s_branch", "loadblk_%d" % k)
+            for k in range(W - 1, -1, -1):
+                self.label("loadblk_%d" % k)
+                self.vload(P.PHYS_WIN + P.RS * k, P.v_voff, S["rs_in"], s("so"))
+                if k > 0:
+                    e("s_sub_u32", s("t1"), s("t1"), 1, comment="SCC = borrow: that was the last pixel")
+                    e("s_cbranch_scc1", "load_done")
+                    e("s_sub_u32", s("so"), s("so"), s("pix"))
+            self.label("load_done")
+            self.tail()
+        for b in range(0 if P.pipe else P.NB):
             for n in range(1, W + 1):
                 self.label("load_b%d_n%d" % (b, n))
                 e("s_mul_i32", s("so"), "m0", s("pix"))
@@ -580,6 +622,19 @@ class Gen:
                 if n > 1:
                     e("s_sub_u32", s("so"), s("so"), s("pix"))
             self.tail(wait="vmcnt(0)" if P.NB == 1 else None)
+        if P.ntload and not P.pipe:
+            for n in range(1, G + 1):
+                self.label("loadnt_n%d" % n)
+                e("s_mul_i32", s("so"), "m0", s("pix"))
+                e("s_mov_b32", "m0", s("safe_m0"))
+                if n != G:
+                    e("s_branch", "loadnt_blk%d" % n)
+            for n in range(G, 0, -1):
+                self.label("loadnt_blk%d" % n)
+                self.vload(P.PHYS_WIN + P.RS * (n - 1), P.v_voff, S["rs_in"], s("so"), nt=True)
+                if n > 1:
+                    e("s_sub_u32", s("so"), s("so"), s("pix"))
+            self.tail(wait="vmcnt(0)")
         # ---- WAIT k ----------------------------------------------------------------------------------------------------------
         for k in range(P.NWAIT):
             self.label("wait_%d" % k)
@@ -633,8 +688,12 @@ class Gen:
         self.label("refill")
         e("s_waitcnt", "vmcnt(0)")
         e("v_mov_b32", vreg(P.v_progA), vreg(P.v_progB))
+        if P.pipe:
+            e("v_mov_b32", vreg(P.v_auxA), vreg(P.v_auxB))
         e("buffer_load_dword", vreg(P.v_progB), vreg(P.v_lane4), s("rs_prog", 4), s("progoff"), offen=True)
-        e("s_add_u32", s("progoff"), s("progoff"), 256)
+        if P.pipe:
+            e("buffer_load_dword", vreg(P.v_auxB), vreg(P.v_lane4), s("rs_prog", 4), s("progoff"), offen=True, offset=256)
+        e("s_add_u32", s("progoff"), s("progoff"), 512 if P.pipe else 256)
         e("s_mov_b32", s("i"), 0)
         self.tail()
 
@@ -873,7 +932,13 @@ class Gen:
         L = dict(VPL=P.VPL, RS=P.RS, K=P.K, G=P.G, W=P.W, MAXD=P.MAXD, MAXA=P.MAXA, R=R, NWAIT=P.NWAIT, BLK=4 * P.VPL // u,
                  M0_SRC1=M0_SRC1, code_bytes=o["__end"], nvgpr=P.nvgpr)
         L["add"] = {key: (o[name] - base) // u for key, name in self.lines.items()}
-        L["load"] = [[0] + [(o["load_b%d_n%d" % (b, n)] - base) // u for n in range(1, P.W + 1)] for b in range(P.NB)]
+        if P.pipe:
+            L["load"] = [[0] + [-1] * P.W]
+            L["loadk"] = [(o["loadk_%d" % k] - base) // u for k in range(P.W)]
+        else:
+            L["load"] = [[0] + [(o["load_b%d_n%d" % (b, n)] - base) // u for n in range(1, P.W + 1)] for b in range(P.NB)]
+        L["pipe"], L["UW"] = P.pipe, P.UW
+        L["loadnt"] = ([0] + [(o["loadnt_n%d" % n] - base) // u for n in range(1, P.G + 1)]) if (P.ntload and not P.pipe) else None
         L["NB"] = P.NB
         L["wait"] = [(o["wait_%d" % k] - base) // u for k in range(P.NWAIT)]
         L["ring"] = P.ring
@@ -898,7 +963,7 @@ class Gen:
             else:
                 line = i.render()
                 # local labels: branch targets and the code_base difference
-                line = re.sub(r"\b(code_base|after_getpc|done|pf_done|pf_loop\d+|load_b\d+_blk\d+|nodiv_\d+_\d+|nostore_\d+_\d+|pf_blk\d+|cp_blk\d+|p_div|p_divd|p_z|p_patch|p_nextz|e_nofetch)\b", lambda m: ".L%s_%s" % (name, m.group(1)), line)
+                line = re.sub(r"\b(code_base|after_getpc|done|pf_done|pf_loop\d+|load_b\d+_blk\d+|loadblk_\d+|loadnt_blk\d+|load_done|nodiv_\d+_\d+|nostore_\d+_\d+|pf_blk\d+|cp_blk\d+|p_div|p_divd|p_z|p_patch|p_nextz|e_nofetch)\b", lambda m: ".L%s_%s" % (name, m.group(1)), line)
                 out.append(line)
         kargs = 0x80 if (P.wta or P.persist) else 0x60
         out += [".Lfunc_end_%s:" % name, ".size %s, .Lfunc_end_%s-%s" % (name, name, name), "",
@@ -964,10 +1029,12 @@ def main():
     ap.add_argument("--ring", type=int, default=0, help="experimental: window rows through an LDS ring of this many slots")
     ap.add_argument("--skip", action="store_true", help="the kernel of the skip programs (unit regions neither divided nor stored)")
     ap.add_argument("--minvgpr", type=int, default=0, help="experiments: allocate at least this many VGPRs (occupancy)")
+    ap.add_argument("--ntload", action="store_true", help="non-temporal loads for region rows of unit-region pixels")
+    ap.add_argument("--pipe", type=int, default=0, help="the window is a program-managed ring of --w slots; the widest unit")
     ap.add_argument("-o", default=None)
     ap.add_argument("--header", default=None)
     a = ap.parse_args()
-    P = Params(vpl=a.vpl, K=a.k, W=a.w, NB=a.nb, PF=a.pf, wta=a.wta, order=a.order, minvgpr=a.minvgpr, skip=a.skip, ring=a.ring, persist=a.persist)
+    P = Params(vpl=a.vpl, K=a.k, W=a.w, NB=a.nb, PF=a.pf, wta=a.wta, order=a.order, minvgpr=a.minvgpr, skip=a.skip, ring=a.ring, persist=a.persist, pipe=a.pipe, ntload=a.ntload)
     g = Gen(P).build()
     if a.o:
         open(a.o, "w").write(g.render())

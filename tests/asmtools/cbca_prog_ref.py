@@ -35,10 +35,14 @@ def band_rows_of(H, K):
 
 def prog_stride_dwords(L):
     """= mccnn::prog::stride_dwords (csrc/cbca_prog_build.h): upper bound of a patch's program in dwords."""
-    K, G, W = L["K"], L["G"], L["W"]
+    K, G, W = L["K"], L["G"], L.get("UW", L["W"])
     rows = 2 * K + 2 * R - 1
     groups = K // 2 if K >= 2 else 1
     pieces = -(-(R + 1) // W)
+    if L.get("pipe"):      # every unit: LOAD + WAIT + its arm runs; every op has a second word (64 ops + 64 words per chunk)
+        n = rows * pieces * (4 * G + 2 * G * groups) + 2
+        n += n // 63 + 1
+        return 2 * (-(-n // 64) * 64)
     n = rows * pieces * (2 * G + 2 * G * groups) + 2
     n += n // 63 + 1
     return -(-n // 64) * 64
@@ -55,7 +59,7 @@ def plan_units(sup0, H, W, y0, x0, L, skip_unit=False):
     lo .. hi of one region row (p_last = pixel index of slot hi relative to the patch's first region row), then the arm
     runs (dir, column j, anchor set, first slot, n) that read them.  skip_unit: anchors whose region is the pixel itself
     take no part (the kernel's skip variant neither divides nor stores them)."""
-    K, G, WW = L["K"], L["G"], L["W"]
+    K, G, WW = L["K"], L["G"], L.get("UW", L["W"])
     MAXD, MAXA = L["MAXD"], L["MAXA"]
     units = []
     up, dn, ok = np.zeros((K, G), int), np.zeros((K, G), int), np.zeros((K, G), bool)
@@ -100,8 +104,10 @@ def plan_units(sup0, H, W, y0, x0, L, skip_unit=False):
         def unit(lo, hi, runs):
             assert 1 <= hi - lo + 1 <= WW
             p = (yq - row0) * W + (x0 - R + hi)
-            assert 0 <= p < 65536, "pixel index exceeds the op's 16-bit field"
-            units.append((lo, hi, p, runs))
+            assert 0 <= p < 65536 or L.get("pipe"), "pixel index exceeds the op's 16-bit field"
+            # single-use row: every pixel of the window is a unit-region pixel (and lies in the patch's own columns)
+            single = R <= lo and hi < R + G and all(unit_region(sup0[yq, x0 - R + v]) for v in range(lo, hi + 1))
+            units.append((lo, hi, p, runs, single))
 
         desc = lambda j, first, n: ("d", j, int(aset[j]), first, n)
         asc = lambda j, first, n: ("a", j, int(aset[j]), first, n)
@@ -166,34 +172,77 @@ def build_program(sup0, H, W, y0, x0, L, skip_unit=False):
     WW, RS, NB = L["W"], L["RS"], L["NB"]
     MAXD, MAXA, BLK = L["MAXD"], L["MAXA"], L["BLK"]
     M0 = L["M0_SRC1"]
-    ops = []
+    ops, aux = [], []
 
-    def emit(op):
+    def emit(op, second=0):
         if len(ops) % 64 == 63:
             ops.append(L["refill"] | (M0 << 16))
+            aux.append(0)
         ops.append(op & 0xffffffff)
+        aux.append(second & 0xffffffff)
 
     units = plan_units(sup0, H, W, y0, x0, L, skip_unit)
 
     def load(i):
-        lo, hi, p, _ = units[i]
-        emit(L["load"][i % NB][hi - lo + 1] | (p << 16))
+        lo, hi, p, _, single = units[i]
+        if single and L.get("loadnt"):
+            emit(L["loadnt"][hi - lo + 1] | (p << 16))
+        else:
+            emit(L["load"][i % NB][hi - lo + 1] | (p << 16))
 
-    def arms(i):
-        lo, hi, p, runs = units[i]
-        wb = (i % NB) * WW                                             # first physical slot of this unit's window
+    def arms(i, wb=None):
+        lo, hi, p, runs, _ = units[i]
+        if wb is None:
+            wb = (i % NB) * WW                                         # first physical slot of this unit's window
         for d, j, aset_all, first, n in runs:
             sf = first - lo
             for aset in decompose(aset_all, L["K"]):                   # aligned groups of anchor rows the kernel has lines for
                 nk = bin(aset).count("1")
                 if d == "d":
-                    assert 1 <= n <= MAXD and 0 <= sf - n + 1 and sf < WW
+                    assert 1 <= n <= MAXD and 0 <= sf - n + 1 and sf < L.get("UW", WW)
                     emit((L["add"][(j, aset, "d")] + (MAXD - n) * BLK * nk) | ((M0 | (RS * (wb + sf - n + 1))) << 16))
                 else:
-                    assert 1 <= n <= MAXA and 0 <= sf and sf + n - 1 < WW
+                    assert 1 <= n <= MAXA and 0 <= sf and sf + n - 1 < L.get("UW", WW)
                     emit((L["add"][(j, aset, "a")] + (MAXA - n) * BLK * nk) | ((M0 | (RS * (wb + sf + n - 1))) << 16))
 
-    if L.get("ring"):
+    if L.get("pipe"):
+        # The window is a ring of WW slots managed HERE (cbca_prog_gen.py, pipe): a unit takes the next free run of
+        # consecutive slots behind the head (a unit that does not fit before the end of the ring starts at slot 0), the
+        # loads of as many upcoming units as fit are issued ahead, and WAIT k - k = slots requested after the unit that
+        # is due - lets exactly that unit arrive before its arms read it.  A slot is requested again only after the
+        # arms that read it (program order), so no load can overtake a reader.
+        pix = L["pix"]
+        head, issued, live = 0, 0, []
+
+        def try_issue():
+            nonlocal head, issued
+            while issued < len(units):
+                lo, hi, p, _, _ = units[issued]
+                n = hi - lo + 1
+                start = 0 if head + n > WW else head
+                if any(start < a + m and a < start + n for a, m in live):
+                    break
+                assert p * pix < 2 ** 31
+                emit(L["loadk"][start + n - 1] | ((n - 1) << 16), p * pix)
+                live.append((start, n))
+                head = start + n
+                issued += 1
+        try_issue()
+        for i in range(len(units)):
+            assert live, "unit %d was never requested" % i
+            emit(L["wait"][sum(m for _, m in live[1:])] | (M0 << 16))
+            arms(i, live[0][0])
+            live.pop(0)
+            try_issue()
+        emit(L["end"] | (M0 << 16))
+        out = np.zeros(-(-len(ops) // 64) * 128, np.uint32)
+        o, a = np.array(ops, np.uint32), np.array(aux, np.uint32)
+        for c in range(0, len(ops), 64):
+            m = min(64, len(ops) - c)
+            out[2 * c:2 * c + m] = o[c:c + m]
+            out[2 * c + 64:2 * c + 64 + m] = a[c:c + m]
+        return out
+    elif L.get("ring"):
         # experimental (cbca_prog_gen.py --ring S): the units travel through an LDS ring of S slots.  PF streams a unit into
         # the next free slots (behind the head; a unit that does not fit there starts at slot 0 - the kernel keeps the
         # same head), as many units ahead as the ring holds; WAIT k lets the oldest unit arrive (k = slots requested after
@@ -204,7 +253,7 @@ def build_program(sup0, H, W, y0, x0, L, skip_unit=False):
         def try_issue():
             nonlocal head, issued
             while issued < len(units):
-                lo, hi, p, _ = units[issued]
+                lo, hi, p, _, _ = units[issued]
                 n = hi - lo + 1
                 start = 0 if head + n > S else head
                 if any(start < a + m and a < start + n for a, m in live):
@@ -269,6 +318,8 @@ def decode_tables(L):
         for n in range(1, maxn + 1):
             add[off + (maxn - n) * L["BLK"] * nk] = (j, aset, d, n)
     load = {off: (b, n) for b, row in enumerate(L["load"]) for n, off in enumerate(row) if n}
+    if L.get("loadnt"):
+        load.update({off: (0, n) for n, off in enumerate(L["loadnt"]) if n})
     wait = {off: k for k, off in enumerate(L["wait"])}
     return add, load, wait
 
@@ -283,10 +334,21 @@ def run_program(prog, vol, H, W, y0, x0, L, sup0):
     win = np.full((WW * L["NB"], D), np.nan, np.float32)
     acc = np.zeros((K, G, D), np.float32)
     pc = 0
+    pipe = L.get("pipe")
+    loadk = {off: k for k, off in enumerate(L["loadk"])} if pipe else {}
     while True:
-        op = int(prog[pc])
+        # (pipe: a 64-op chunk is followed by the 64 second words of its ops)
+        op = int(prog[(pc // 64) * 128 + pc % 64]) if pipe else int(prog[pc])
+        second = int(prog[(pc // 64) * 128 + 64 + pc % 64]) if pipe else 0
         pc += 1
         off, par = op & 0xffff, op >> 16
+        if off in loadk and off != L["end"] and off != L["refill"] and off not in wait:
+            k, n = loadk[off], (par & 0xff) + 1
+            assert second % L["pix"] == 0
+            p = second // L["pix"]
+            for e in range(n):
+                win[k - e] = flat[row0 * W + p - e]
+            continue
         if off == L["end"]:
             break
         if off == L["refill"]:

@@ -69,9 +69,11 @@ def test_size_model_matches_the_assembler(tmp_path, vpl, w, nb, k):
 
 @pytest.mark.parametrize("H,W,D,seed,flat", [(12, 17, 8, 0, False), (30, 41, 5, 1, False), (9, 33, 4, 2, True),
                                                (40, 48, 6, 3, False)])
-@pytest.mark.parametrize("w,nb,k", [(12, 1, 2), (8, 1, 2), (10, 2, 2), (6, 2, 2), (20, 1, 4), (12, 1, 4), (16, 1, 1)])
-def test_programs_reproduce_the_oracle_op_level(H, W, D, seed, flat, w, nb, k):
-    L = gen.Gen(gen.Params(vpl=4, K=k, W=w, NB=nb)).build().layout()
+@pytest.mark.parametrize("w,nb,k,pipe", [(12, 1, 2, 0), (8, 1, 2, 0), (10, 2, 2, 0), (6, 2, 2, 0), (20, 1, 4, 0), (12, 1, 4, 0),
+                                          (16, 1, 1, 0), (42, 1, 4, 21), (42, 1, 4, 42), (24, 1, 4, 7), (30, 1, 2, 12)])
+def test_programs_reproduce_the_oracle_op_level(H, W, D, seed, flat, w, nb, k, pipe):
+    L = gen.Gen(gen.Params(vpl=4, K=k, W=w, NB=nb, pipe=pipe)).build().layout()
+    L["pix"] = 4 * D
     img, vol = make_case(H, W, D, seed, flat)
     sup0 = support_words(img)
     want = oracle_cbca(img, vol)
@@ -128,6 +130,7 @@ def simulate(g, L, img, vol, code_addr=0x7e00fffff000, out_init=None):
     VPL = P.VPL
     Dp = -(-D // 4) * 4 if VPL != 3 else -(-D // 3) * 3
     sup0 = support_words(img)
+    L = dict(L, pix=4 * Dp)
     progs, meta = ref.build_all(sup0, H, W, L, skip_unit=P.skip)
     hwd = np.zeros((H, W, Dp), np.float32)
     hwd[:, :, :D] = vol.transpose(1, 2, 0)
@@ -165,10 +168,15 @@ def simulate(g, L, img, vol, code_addr=0x7e00fffff000, out_init=None):
                                                        (3, 12, 1, 14, 23, 6, 4, False), (2, 12, 1, 11, 16, 6, 5, False),
                                                        (4, 8, 1, 13, 21, 5, 6, True), (4, 12, 1, 7, 12, 300, 7, False),
                                                        (4, 10, 2, 12, 17, 8, 0, False), (4, 6, 2, 9, 33, 4, 2, True),
-                                                       (3, 10, 2, 14, 23, 6, 4, False)])
+                                                       (3, 10, 2, 14, 23, 6, 4, False),
+                                                       # nb = 0: the program-managed ring of 42 slots, widest unit w
+                                                       (4, 21, 0, 12, 17, 8, 0, False), (4, 42, 0, 9, 33, 4, 2, True),
+                                                       (3, 21, 0, 14, 23, 6, 4, False), (2, 21, 0, 11, 16, 6, 5, False),
+                                                       (4, 9, 0, 13, 21, 5, 6, True), (4, 21, 0, 7, 12, 300, 7, False),
+                                                       (4, 21, 0, 40, 48, 4, 3, False)])
 @pytest.mark.parametrize("k", [2, 4])
 def test_generated_kernel_reproduces_the_oracle_in_the_simulator(vpl, w, nb, H, W, D, seed, flat, k):
-    g = gen.Gen(gen.Params(vpl=vpl, K=k, W=w, NB=nb)).build()
+    g = gen.Gen(gen.Params(vpl=vpl, K=k, W=w if nb else 42, NB=nb or 1, pipe=0 if nb else w)).build()
     L = g.layout()
     img, vol = make_case(H, W, D, seed, flat)
     got, st = simulate(g, L, img, vol)

@@ -29,13 +29,15 @@ K_DEFAULT = 2
 RING = 0
 MINVGPR = 0
 PERSIST = False
+PIPE = 0
+NTLOAD = False
 
 
 def build_hsaco(vpl, w, outdir, nb=1, debug=0, pf=0, k=None):
     k = k or K_DEFAULT
     os.makedirs(outdir, exist_ok=True)
-    g = gen.Gen(gen.Params(vpl=vpl, K=k, W=w, NB=nb, debug=debug, PF=pf, ring=RING, minvgpr=MINVGPR, persist=PERSIST)).build()
-    base = os.path.join(outdir, "cbca_prog_v%d_k%d_w%d_b%d_g%d_p%d_r%d_m%d_s%d" % (vpl, k, w, nb, debug, pf, RING, MINVGPR, int(PERSIST)))
+    g = gen.Gen(gen.Params(vpl=vpl, K=k, W=w, NB=nb, debug=debug, PF=pf, ring=RING, minvgpr=MINVGPR, persist=PERSIST, pipe=PIPE, ntload=NTLOAD)).build()
+    base = os.path.join(outdir, "cbca_prog_v%d_k%d_w%d_b%d_g%d_p%d_r%d_m%d_s%d_q%d_n%d" % (vpl, k, w, nb, debug, pf, RING, MINVGPR, int(PERSIST), PIPE, int(NTLOAD)))
     if not os.path.exists(base + ".hsaco") or os.path.getmtime(base + ".hsaco") < os.path.getmtime(gen.__file__):
         open(base + ".s", "w").write(g.render())
         subprocess.check_call([LLVM + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c",
@@ -97,10 +99,10 @@ def timeit(fn, iters):
     return a.elapsed_time(b) / iters
 
 
-def programs_for(sup, H, W, L):
+def programs_for(sup, H, W, L, Dp=0):
     sup0 = sup.cpu().numpy().view(np.uint32).reshape(H, W)
     t = time.time()
-    progs, meta = ref.build_all(sup0, H, W, L)
+    progs, meta = ref.build_all(sup0, H, W, dict(L, pix=4 * Dp))
     meta["build_s"] = time.time() - t
     return torch.from_numpy(progs.view(np.int32)).cuda(), meta
 
@@ -117,7 +119,7 @@ def check_shape(mod, g, L, H, W, D, seed, flat=False):
     gt = torch.Generator(device="cuda").manual_seed(seed)
     a = (torch.rand((H, W, Dp), device="cuda", generator=gt) * 3 - 2).contiguous()
     want, _ = sd.cbca_hwd(a, torch.full_like(a, float("nan")), sup, D, 1, 14)
-    progs, meta = programs_for(sup, H, W, L)
+    progs, meta = programs_for(sup, H, W, L, Dp)
     out = torch.full_like(a, float("nan"))
     nchunks = -(-Dp // (64 * P.VPL))
     mod.launch(grid_of(meta, nchunks), kargs([a, a], [out, out], [progs, progs], [sup, sup], Dp, H, W, nchunks, meta))
@@ -141,9 +143,11 @@ def main():
     ap.add_argument("--k", type=int, default=2); ap.add_argument("--order", type=int, default=0)
     ap.add_argument("--ring", type=int, default=0, help="experimental: window rows through an LDS ring of this many slots")
     ap.add_argument("--minvgpr", type=int, default=0); ap.add_argument("--persist", action="store_true")
+    ap.add_argument("--pipe", type=int, default=0, help="the window is a program-managed ring of --w slots; widest unit")
+    ap.add_argument("--ntload", action="store_true", help="non-temporal loads for rows of unit-region pixels")
     args = ap.parse_args()
-    global K_DEFAULT, RING, MINVGPR, PERSIST
-    K_DEFAULT, RING, MINVGPR, PERSIST = args.k, args.ring, args.minvgpr, args.persist
+    global K_DEFAULT, RING, MINVGPR, PERSIST, PIPE, NTLOAD
+    K_DEFAULT, RING, MINVGPR, PERSIST, PIPE, NTLOAD = args.k, args.ring, args.minvgpr, args.persist, args.pipe, args.ntload
     hip.require_device()
     allok = True
     for vpl in (() if args.skip_small else (4,) if RING else (4, 2, 3)):   # (no 8-byte buffer_load ... lds on gfx950)
@@ -168,8 +172,8 @@ def main():
     Li, Ri, _, _, _ = synthetic.make_pair(H, W, D, seed=100)
     dl, dr = torch.from_numpy(Li[:, :, 0]).cuda(), torch.from_numpy(Ri[:, :, 0]).cuda()
     sl, sr = sd.cross_arms_pair(dl, dr, 0.02, 14)
-    pl, meta = programs_for(sl, H, W, L)
-    pr, meta_r = programs_for(sr, H, W, L)
+    pl, meta = programs_for(sl, H, W, L, Dp)
+    pr, meta_r = programs_for(sr, H, W, L, Dp)
     print("program build (python): %.1f s + %.1f s; longest %d / %d of stride %d dwords" % (
         meta["build_s"], meta_r["build_s"], meta["longest"], meta_r["longest"], meta["stride"]), flush=True)
     used = int((pl.view(-1, meta["stride"]) != 0).sum()) * 4
@@ -189,7 +193,7 @@ def main():
     print("full size bit-exact vs cbca_hwd: left %s right %s" % (torch.equal(b, want_l), torch.equal(d, want_r)), flush=True)
     vb = 4.0 * H * W * D
     ms = timeit(lambda: mod.launch(grid_of(meta, nchunks * 2), ka), args.iters)
-    print("K=%d W=%d NB=%d regs=%d" % (g.P.K, args.w, args.nb, g.P.nvgpr))
+    print("K=%d W=%d NB=%d pipe=%d regs=%d" % (g.P.K, args.w, args.nb, PIPE, g.P.nvgpr))
     print("cbca_prog pair      %8.4f ms  %6.1f GB/s (%.1f%% of 8 TB/s)" % (ms, 4 * vb / ms / 1e6, 4 * vb / ms / 1e6 / 80), flush=True)
     for pf in [int(x) for x in args.pf.split(",") if x]:
         g2, path2 = build_hsaco(vpl, args.w, os.path.join(ROOT, "mc-cnn-python_amd", "build", "asm"), args.nb, 0, pf)
@@ -219,7 +223,7 @@ def main():
             ms = timeit(lambda: mod.launch(grid, ka, lds), args.iters)
             print("  with %d B of LDS per wave (%d waves per SIMD at most): %8.4f ms" % (lds, 163840 // lds // 4, ms), flush=True)
         # timing only (wrong results): ops replaced by WAIT 0 / kernels without division or stores
-        loads = set(x for row in L["load"] for x in row[1:])
+        loads = set(L["loadk"]) if PIPE else set(x for row in L["load"] for x in row[1:])
         special = loads | set(L["wait"]) | {L["end"], L["refill"]}
         nop = L["wait"][0] | (L["M0_SRC1"] << 16)
 

@@ -26,7 +26,7 @@ def units(rg,cg,skip):
     y0,x0=rg*K,cg*G
     us=ref.plan_units(sup,H,W,y0,x0,L,skip_unit=skip)
     row0=max(y0-13,0); out=[]
-    for lo,hi,p,runs in us:
+    for lo,hi,p,runs,_ in us:
         yq=row0+p//W; xhi=p%W; n=hi-lo+1
         adds=sum(r[4]*bin(r[2]).count('1') for r in runs)
         nops=1+sum(len(ref.decompose(r[2],K)) for r in runs)

@@ -27,7 +27,7 @@ def patch_units(K,G,WW,rg,cg):
     y0,x0=rg*K,cg*G
     row0=max(y0-R,0)
     out=[]
-    for lo,hi,p,runs in ref.plan_units(sup,H,W,y0,x0,L):
+    for lo,hi,p,runs,_ in ref.plan_units(sup,H,W,y0,x0,L):
         yq=row0+p//W; xhi=p%W   # p=(yq-row0)*W+(x0-R+hi)
         n=hi-lo+1
         adds=sum(r[4]*bin(r[2]).count('1') for r in runs)

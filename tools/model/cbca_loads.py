@@ -27,7 +27,7 @@ def model(K,G,WW,nsamp=600):
     for i in idx:
         rg,cg=divmod(int(i),cgs)
         us=ref.plan_units(sup,H,W,rg*K,cg*G,L)
-        for lo,hi,p,rr in us:
+        for lo,hi,p,rr,_ in us:
             slots+=hi-lo+1; units+=1
             for d,j,aset,first,n in rr:
                 for m in ref.decompose(aset,K):
