@@ -195,15 +195,19 @@ int mccnn_cbca_iter_prog_pair_wta(const float *in_left, float *out_left, const m
                                   float *disparity_left, float *disparity_right, int store_right, mccnn_stream_t stream);
 
 /* A later iteration of the SAME ping-pong pair of buffers, without the pixels that cannot change any more.  A pixel
- * whose support region is the pixel itself (all four arms 0: count 1) gets (0 + x) / 1 = x (pf:156-161), so after two
- * consecutive iterations in -> out, out -> in both buffers hold its final value (the first iteration turns a -0.0 into
- * +0.0, the second copies that back).  From the THIRD consecutive iteration on this entry point may replace
- * mccnn_cbca_iter_prog_pair: it runs the second program set, which mccnn_cbca_prog_build_skip_pair writes into the same
- * buffers (a launch of its own, so that it can run beside the first iterations; such anchors take no
- * part: not loaded for their own sake, not divided, NOT STORED) - same bits in every pixel of out_*, fewer bytes moved
- * (on the synthetic benchmark pair 46 % of the pixels: 27 % less HBM traffic per iteration).  The caller's promise:
- * out_* already holds, for every such pixel, what in_* holds.  match.py's 16-iteration aggregation (pf:117-183 called
- * with max_average_time = 16) runs iterations 3 .. 15 this way; the last one carries the WTA and needs every pixel. */
+ * whose support region is the pixel itself (all four arms 0: count 1) gets v1 = (0 + v0) / 1 in the first iteration
+ * (pf:156-161) - v0 except that -0.0 becomes +0.0 and a signalling NaN is quieted - and (0 + v1) / 1 = v1 bit for bit
+ * ever after.  This entry point may replace mccnn_cbca_iter_prog_pair from the SECOND consecutive iteration on: it runs
+ * the second program set, which mccnn_cbca_prog_build_skip_pair writes into the same buffers (a launch of its own, so
+ * that it can run beside the first iterations); such anchors take no part - not loaded for their own sake, not divided,
+ * NOT STORED (on the synthetic benchmark pair 46 % of the pixels: 27 % less HBM traffic per iteration).  What the
+ * caller must know: out_* keeps, for every such pixel, what it held before.  After a first full iteration in -> out
+ * that is v1 in `out` and still v0 in `in`; as an operand of somebody else's sum the two are interchangeable (a sum
+ * that began as 0 + x is never -0.0, so adding -0.0 or +0.0 gives the same bits; either NaN gives the same quiet NaN),
+ * but a caller that READS such a pixel from the buffer that was the first iteration's input must first run one full
+ * iteration into it.  match.py's 16-iteration aggregation (pf:117-183 with max_average_time = 16) therefore runs
+ * iteration 1 full, iterations 2 .. 15 this way, and the last one - which carries the WTA and writes every pixel
+ * into the first iteration's input buffer - full again (stereo_device.cbca_prog_pair states the rule for any count). */
 int mccnn_cbca_prog_build_skip_pair(const mccnn_support_t *support_left, const mccnn_support_t *support_right, int D,
                                     int H, int W, int L, void *prog_left, void *prog_right, mccnn_stream_t stream);
 int mccnn_cbca_iter_prog_pair_skip(const float *in_left, float *out_left, const mccnn_support_t *support_left,

@@ -10,6 +10,7 @@
 //
 // The assembled code objects are embedded in this library (build/asm/cbca_prog_v{2,3,4}.inc, Makefile) and loaded
 // through the HIP module API on first use, once per device.
+#include <iterator>
 #include <mutex>
 #include <unordered_map>
 
@@ -289,9 +290,17 @@ static int prog_build(const char *who, int set, const mccnn_support_t *support_l
                        s.stride, prog::set_bytes(s) / 4, set);
     rc = check_launch(who);
     if (rc == 0) {
+        const unsigned long long gl = support_generation(support_left), gr = support_generation(support_right);
         std::lock_guard<std::mutex> lock(prog::g_built_mu);
-        prog::g_built[set][prog_left] = prog::Built{D, H, W, support_left, support_generation(support_left)};
-        prog::g_built[set][prog_right] = prog::Built{D, H, W, support_right, support_generation(support_right)};
+        auto &reg = prog::g_built[set];
+        // bounded like the support registry: past 4096 entries the ones built from the oldest support arms go (their
+        // generations are 2048+ mccnn_cross_arms calls behind: such programs are stale or their buffers long freed)
+        if (reg.size() > 4096) {
+            const unsigned long long newest = gl > gr ? gl : gr, keep_from = newest > 2048 ? newest - 2048 : 0;
+            for (auto it = reg.begin(); it != reg.end();) it = it->second.gen <= keep_from ? reg.erase(it) : std::next(it);
+        }
+        reg[prog_left] = prog::Built{D, H, W, support_left, gl};
+        reg[prog_right] = prog::Built{D, H, W, support_right, gr};
     }
     return rc;
 }

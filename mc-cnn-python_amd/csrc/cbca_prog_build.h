@@ -96,8 +96,9 @@ MCCNN_PROG_HD uint64_t sched_of(bool ok, int K, int k, int up, int dn, int nd)
 
 // sup0: plane 0 of the support buffer ([H][W] words: bits 0-4 up, 5-9 down, 10-14 left, 15-19 right).
 // skip_unit: anchors whose support region is the pixel itself (all four arms 0) take no part.  (0 + x) / 1 = x (pf:156-
-// 161 with aver_num = 1), so from the third consecutive iteration of a ping-pong pair on both buffers already hold such
-// a pixel's value: the "skip" programs neither read it for its own sake nor does the skip kernel write it.
+// 161 with aver_num = 1) up to the sign of a zero, so after the first iteration of a ping-pong pair both buffers hold
+// a value of such a pixel that every later sum treats alike (include/mccnn.h, mccnn_cbca_iter_prog_pair_skip): the
+// "skip" programs neither read it for its own sake nor does the skip kernel write it.
 MCCNN_PROG_HD bool unit_region(uint32_t word) { return (word & 0xfffffu) == 0u; }
 
 MCCNN_PROG_HD void patch_setup(const Layout &L, const uint32_t *sup0, int H, int W, int y0, int x0, Patch &P,

@@ -148,7 +148,9 @@ __global__ __launch_bounds__(256) void conv1_split_kernel(const float *__restric
                 for (int k = 0; k < 9; ++k) acc += w[c * 9 + k] * v[k];
                 acc += bias[c];
                 y[j] = fmaxf(acc, 0.f);
-                sat |= !(y[j] * act_scale <= 65504.f);        // also true for NaN
+                // above the records' range - or a NaN, tested BEFORE the ReLU (fmaxf drops a NaN operand, and a NaN
+                // pixel must not come out as a clean 0: the pair then goes to the library path, which propagates it)
+                sat |= !(acc * act_scale <= 65504.f);
             }
             split4(y, act_scale, hi[g], lo[g]);
         }
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
 
         // ---- epilogue: this wave's four rows of 32 pixels ----
         const int px = lane & 31, half = lane >> 5;
-        int satbits = 0;
+        bool sat = false;
 #ifdef CONV_ABL_NOEPI   // timing experiment: one store per accumulator so the MFMAs stay live
         {
             float t = 0.f;
@@ -396,9 +398,9 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
                                     const int r = 4 * g + q;
                                     const float t = fmaf(acc[nb][mb][r] + accx[nb][mb][r], inv_scale * act_scale,
                                                          bias[ch + q] * act_scale);
-                                    // largest value seen, compared as integers (positive floats order like their bit
-                                    // patterns, negative ones are negative integers, a NaN is above every finite value)
-                                    satbits = max(satbits, __float_as_int(t));
+                                    // above the records' range, or a NaN of either sign (a negative value is not: the
+                                    // ReLU makes it 0) - the same test as conv1_split's
+                                    sat |= !(t <= 65504.f);
                                     y4[q] = __builtin_amdgcn_fmed3f(t, 0.f, 65504.f);
                                 }
                                 split4_scaled(y4, hi, lo);
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
         }
         // a stored activation left the f16 range of the records (|x| * act_scale > 65504): the clamp keeps the data
         // finite, the flag tells the host that this pair's features are not float32-accurate (mccnn.h)
-        if (MODE == 0 && sat_flag && __builtin_amdgcn_ballot_w64(satbits > __float_as_int(65504.f)) != 0 && lane == 0)
+        if (MODE == 0 && sat_flag && __builtin_amdgcn_ballot_w64(sat) != 0 && lane == 0)
             atomicOr(sat_flag, 1);
 #endif
         if (vn >= total) break;

@@ -15,6 +15,7 @@
 //                       bit-exact; its separable variant serves distances > 14.
 #include <math.h>
 
+#include <iterator>
 #include <mutex>
 #include <unordered_map>
 
@@ -940,7 +941,14 @@ static int launch_cross_arms(const float *img0, const float *img1, mccnn_support
     rc = check_launch("mccnn_cross_arms(order)");
     if (rc == 0) {
         std::lock_guard<std::mutex> lock(g_support_mu);
-        if (g_support.size() > 4096) g_support.clear();   // bounded: stale entries only cost a missed check
+        // The registry is authoritative (the *_hwd / *_prog entry points refuse buffers it does not know), so it is never
+        // emptied: when it outgrows its bound only the OLDEST half goes - buffers whose arms were written 2048+
+        // mccnn_cross_arms calls ago (long freed, or due for a rewrite before their next use anyway).
+        if (g_support.size() > 4096) {
+            const unsigned long long keep_from = g_support_gen > 2048 ? g_support_gen - 2048 : 0;
+            for (auto it = g_support.begin(); it != g_support.end();)
+                it = it->second.gen <= keep_from ? g_support.erase(it) : std::next(it);
+        }
         g_support[sup0] = SupportInfo{H, W, L, ++g_support_gen};
         g_support[sup1] = SupportInfo{H, W, L, ++g_support_gen};
     }

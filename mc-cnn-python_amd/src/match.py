@@ -152,6 +152,7 @@ def main(argv=None):
             cv_mode=hip.MCCNN_CV_MFMA if args.fast else hip.MCCNN_CV_EXACT,
             cbca_order=hip.MCCNN_CBCA_SEPARABLE if (args.fast and args.separable_cbca) else hip.MCCNN_CBCA_REFERENCE_ORDER,
             features=features,
+            on_saturation="ignore",      # several pairs may be in flight: finish() polls the flag and repeats them
             extras=dict(both_view_support=args.paper_support_regions,
                         interpolation_directions=16 if args.paper_interpolation else 4,
                         occlusion_from_left=args.paper_interpolation, numpy1_promotion=args.numpy1_promotion))

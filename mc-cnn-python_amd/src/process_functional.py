@@ -126,7 +126,7 @@ def cost_volume_aggregation(left_image, right_image, left_cost_volume, right_cos
     if not CBCA_BOTH_VIEWS and CBCA_ORDER == "reference" and int(distance_threshold) <= 14:
         # What match.py's default runs: the reference's summation order on pixel-major copies, both views per launch,
         # through the program-driven assembly kernel (its programs are built once here and serve every iteration; from
-        # the third iteration on the pixels whose support region is the pixel itself are left alone - same bits).
+        # the second iteration on the pixels whose support region is the pixel itself are left alone - same bits).
         vl, was_np = _dev(left_cost_volume)
         vr, _ = _dev(right_cost_volume)
         D, H, W = vl.shape

@@ -336,7 +336,7 @@ def cbca_prog_buffers(D, H, W, device):
 def cbca_prog_build_pair(support_l, support_r, D, distance_threshold, progs, which="both"):
     """Compiles both images' support regions into the per-patch programs of the assembly aggregation kernel: once per
     pair, after cross_arms_pair, for all iterations.  which: "full" (mccnn_cbca_prog_build_pair: what every iteration can
-    run), "skip" (mccnn_cbca_prog_build_skip_pair: the second set in the same buffers, which third and later iterations
+    run), "skip" (mccnn_cbca_prog_build_skip_pair: the second set in the same buffers, which second and later iterations
     run, cbca_prog_pair) or "both" - two launches, so a caller may put the second one beside the first iterations."""
     H, W = support_l.shape
     _check_support(support_l, H, W, "cbca_prog_build_pair")
@@ -357,9 +357,16 @@ def cbca_prog_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, progs, D, i
     `progs` from cbca_prog_build_pair on the same support buffers and D.  Same ping-pong contract; wta_out /
     store_right as in cbca_hwd_pair (mccnn_cbca_iter_prog_pair_wta for the last iteration).
 
-    skip_unit_regions: from the third iteration on, pixels whose support region is the pixel itself are left alone
-    (mccnn_cbca_iter_prog_pair_skip): (0 + x) / 1 = x, and after iterations 1 and 2 both ping-pong buffers hold that
-    value - the same bits everywhere, fewer bytes moved.  The iteration that carries the WTA runs the full programs.
+    skip_unit_regions: from the SECOND iteration on, pixels whose support region is the pixel itself are left alone
+    (mccnn_cbca_iter_prog_pair_skip).  Such a pixel gets v1 = (0 + v0) / 1 in the first iteration (pf:156-161 with
+    aver_num = 1), which is v0 except that -0.0 becomes +0.0 and a signalling NaN is quieted, and (0 + v1) / 1 = v1 bit
+    for bit ever after.  The first iteration (full programs) puts v1 into the partner buffer; the input buffer keeps v0.
+    Every later iteration may skip these pixels: as a NEIGHBOUR in somebody else's region v0 and v1 give the same sum
+    bit for bit (a running sum that started as 0 + x is never -0.0, so adding -0.0 or +0.0 cannot differ; a NaN operand
+    gives the same quiet NaN either way), and nothing else reads them - except the caller, from the final buffer.  With
+    an even number of iterations that is the input buffer (v0!), so the last iteration then runs the full programs and
+    rewrites every pixel; with an odd number it is the partner buffer, which has held v1 since the first iteration.
+    The iteration that carries the WTA runs the full programs anyway.  Same bits everywhere, fewer bytes moved.
     skip_ready: an event after which the second program set is complete when it was built on another stream (the
     current stream waits for it in front of the first iteration that needs it)."""
     H, W, Dp = vol_l.shape
@@ -375,9 +382,12 @@ def cbca_prog_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, progs, D, i
     n = int(iterations)
     if wta_out is not None and (n < 1 or D > cbca_hwd_wta_max_d()):
         raise ValueError("cbca_prog_pair: the fused WTA needs at least one iteration and D <= %d" % cbca_hwd_wta_max_d())
+    waited = False
     for it in range(n):
         fused = wta_out is not None and it == n - 1
-        timer.start("cbca_iter_prog_pair_skip" if skip_unit_regions and it >= 2 and not fused else "cbca_iter_prog_pair")
+        # (see the docstring) not the first iteration, and not the one that leaves the result in the input buffer
+        skip = bool(skip_unit_regions) and it >= 1 and not fused and not (n % 2 == 0 and it == n - 1)
+        timer.start("cbca_iter_prog_pair_skip" if skip else "cbca_iter_prog_pair")
         if fused:
             for t in wta_out:
                 if tuple(t.shape) != (H, W) or t.dtype != torch.float32 or not t.is_contiguous():
@@ -389,9 +399,10 @@ def cbca_prog_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, progs, D, i
                       "mccnn_cbca_iter_prog_pair_wta")
         else:
             fn, who = ((lib.mccnn_cbca_iter_prog_pair_skip, "mccnn_cbca_iter_prog_pair_skip")
-                       if skip_unit_regions and it >= 2 else (lib.mccnn_cbca_iter_prog_pair, "mccnn_cbca_iter_prog_pair"))
-            if skip_ready is not None and skip_unit_regions and it == 2:
+                       if skip else (lib.mccnn_cbca_iter_prog_pair, "mccnn_cbca_iter_prog_pair"))
+            if skip_ready is not None and skip and not waited:
                 torch.cuda.current_stream().wait_event(skip_ready)
+                waited = True
             hip.check(fn(hip.ptr(sl), hip.ptr(dl), hip.ptr(support_l), hip.ptr(progs[0]), hip.ptr(sr), hip.ptr(dr),
                          hip.ptr(support_r), hip.ptr(progs[1]), int(D), H, W, int(distance_threshold), hip.stream()), who)
         timer.stop()
@@ -626,12 +637,17 @@ class StereoMatcher(object):
     tolerance-bounded variant of those two stages.  NOTE (round 3 on): the defaults are the bit-exact variants
     (MCCNN_CV_EXACT, MCCNN_CBCA_REFERENCE_ORDER: 13.7 ms per Middlebury-half pair); callers that relied on the
     earlier default (the fast variants, 9.3 ms) must ask for MCCNN_CV_MFMA / MCCNN_CBCA_SEPARABLE explicitly.
-    features_saturated() tells (with one host synchronisation) whether a pair since the last check drove an
-    activation out of the split records' range - the caller then repeats that pair with features="miopen".
+    on_saturation: what match() / match_graph() do when the hand-written feature kernels report that an activation
+    left the range of their stored records (|x| >= 255.9: the data was clamped, the features of that pair are not
+    float32-accurate).  "fallback" (default): the flag is read after every pair - ONE host synchronisation per pair -
+    and such a pair is matched again with the float32 library convolutions; "raise": RuntimeError instead; "ignore":
+    nothing is read and nothing blocks - for callers that keep several pairs in flight and poll
+    features_saturated() themselves (match.py, bench.py).
     """
 
     def __init__(self, net, hp=None, cv_mode=hip.MCCNN_CV_EXACT, cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER,
-                 feature_tile_rows=None, extras=None, features="auto", layout="auto", cbca_kernel="auto"):
+                 feature_tile_rows=None, extras=None, features="auto", layout="auto", cbca_kernel="auto",
+                 on_saturation="fallback", skip_unit_regions=True):
         self.device = hip.require_device()
         self.net = net
         self.hp = dict(DEFAULT_HP)
@@ -661,6 +677,13 @@ class StereoMatcher(object):
         if cbca_kernel not in ("auto", "prog", "hwd"):
             raise ValueError("cbca_kernel must be 'auto', 'prog' or 'hwd'")
         self.cbca_kernel = cbca_kernel
+        if on_saturation not in ("fallback", "raise", "ignore"):
+            raise ValueError("on_saturation must be 'fallback', 'raise' or 'ignore'")
+        self.on_saturation = on_saturation
+        self._library_twin = None
+        # cbca_prog_pair's rule (iterations that leave unit-region pixels alone: same bits, fewer bytes); False runs the
+        # full programs in every iteration - the content-independent cost of the aggregation (bench.py reports both)
+        self.skip_unit_regions = bool(skip_unit_regions)
         # opt-in departures from the reference (they change the output): the paper's rules it leaves out, and the
         # scalar promotion of the NumPy it was written for
         self.extras = dict(both_view_support=False, interpolation_directions=4, occlusion_from_left=False,
@@ -710,7 +733,33 @@ class StereoMatcher(object):
                 and not self.extras["both_view_support"]
                 and int(self.hp["cbca_distance"]) <= 14)
 
+    def _saturated_pair(self, left_image, right_image, ndisp, out):
+        """on_saturation for the pair that has just been launched: None when its features were fine (or nobody is to
+        look), else the map of the same pair behind the float32 library convolutions (written to `out` if given)."""
+        if self.features != "split_f16" or self.on_saturation == "ignore" or torch.cuda.is_current_stream_capturing():
+            return None
+        if not self.features_saturated():
+            return None
+        if self.on_saturation == "raise":
+            raise RuntimeError("StereoMatcher: an activation left the range of the split-operand feature kernels "
+                               "(|x| >= 255.9); match this pair with features='miopen'")
+        if self._library_twin is None:
+            self._library_twin = StereoMatcher(self.net, hp=self.hp, cv_mode=self.cv_mode, cbca_order=self.cbca_order,
+                                               extras=self.extras, features="miopen", layout=self.layout,
+                                               cbca_kernel=self.cbca_kernel, on_saturation="ignore")
+        return self._library_twin.match(left_image, right_image, ndisp, out=out)
+
     def match(self, left_image, right_image, ndisp, timer=_NO_TIMER, keep=None, _static_out=False, out=None):
+        """_match() + the on_saturation policy (class docstring): a pair whose hand-written features were clamped is
+        matched again with the library convolutions unless the caller asked to be left alone."""
+        res = self._match(left_image, right_image, ndisp, timer=timer, keep=keep, _static_out=_static_out, out=out)
+        if keep is None and not _static_out:
+            redo = self._saturated_pair(left_image, right_image, ndisp, out)
+            if redo is not None:
+                return redo
+        return res
+
+    def _match(self, left_image, right_image, ndisp, timer=_NO_TIMER, keep=None, _static_out=False, out=None):
         """left/right: standardised float32 device tensors [H,W] (or [H,W,1]).  Returns the final left disparity
         map [H,W] on the device.  The matcher's workspace is reused by the next call, so the map is handed out as a
         copy - one [H,W] allocation + one copy per pair; pass `out` (a contiguous float32 [H,W] device tensor) and the
@@ -731,7 +780,7 @@ class StereoMatcher(object):
         sides = [hip.MCCNN_SIDE_LEFT, hip.MCCNN_SIDE_RIGHT]
 
         # The support arms and the aggregation programs depend on the images only: without per-stage timing they run
-        # on a side stream - arms + full programs beside the cost volume, the skip programs (first needed by the third
+        # on a side stream - arms + full programs beside the cost volume, the skip programs (first needed by the second
         # iteration of the second aggregation) beside the first aggregation and SGM.  Measured at cfg2 (one box, 100
         # pairs each, twice): everything on the main stream 9.22 / 9.22 ms, everything beside the conv stack 9.19 /
         # 9.12 (the builder's waves slow the matrix-core kernels down by what they save), this placement 9.14 / 9.06.
@@ -751,7 +800,7 @@ class StereoMatcher(object):
                         cbca_prog_build_pair(sup_l, sup_r, D, hp["cbca_distance"], ws["progs"], "full")
                     full_ready = torch.cuda.Event()
                     full_ready.record(self._side)
-                elif ws["progs"] is not None:
+                elif ws["progs"] is not None and self.skip_unit_regions:
                     cbca_prog_build_pair(sup_l, sup_r, D, hp["cbca_distance"], ws["progs"], "skip")
                     skip_ready = torch.cuda.Event()
                     skip_ready.record(self._side)
@@ -805,7 +854,8 @@ class StereoMatcher(object):
                 if progs is None:
                     return cbca_hwd_pair(lh, lt, sup_l, rh, rt, sup_r, D, int(n), hp["cbca_distance"], timer, **kw)
                 return cbca_prog_pair(lh, lt, sup_l, rh, rt, sup_r, progs, D, int(n), hp["cbca_distance"], timer,
-                                      skip_ready=skip_ready if overlap else None, **kw)
+                                      skip_ready=skip_ready if overlap else None,
+                                      skip_unit_regions=self.skip_unit_regions, **kw)
 
             (lh, lt), (rh, rt) = aggregate_hwd(lh, as_hwd(b0), rh, as_hwd(b1), hp["cbca_num_iterations1"])
             if keep is not None:
@@ -908,15 +958,16 @@ class StereoMatcher(object):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):
-                    self.match(sl, sr, ndisp)
+                    self._match(sl, sr, ndisp)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                out = self.match(sl, sr, ndisp, _static_out=True)
+                out = self._match(sl, sr, ndisp, _static_out=True)
             g = (graph, sl, sr, out)
             self._graphs[key] = g
         graph, sl, sr, out = g
         sl.copy_(L)
         sr.copy_(R)
         graph.replay()
+        self._saturated_pair(sl, sr, ndisp, out)      # on_saturation (one host synchronisation unless "ignore")
         return out

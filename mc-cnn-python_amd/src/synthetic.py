@@ -37,8 +37,10 @@ def standardize(gray_u8):
     return np.expand_dims(img.astype(np.float32), axis=2)
 
 
-def make_scene_u8(height, width, ndisp, seed=0):
-    """Returns (left_u8 [H,W], right_u8 [H,W], true_disparity_of_right_pixels [H,W] int32)."""
+def make_scene_u8(height, width, ndisp, seed=0, texture=True):
+    """Returns (left_u8 [H,W], right_u8 [H,W], true_disparity_of_right_pixels [H,W] int32).  texture=False: the second
+    scene class - the flat blobs alone, no fine texture anywhere: almost every pixel has long support arms (the
+    aggregation's most expensive kind of image; a few per cent of unit-region pixels instead of almost half)."""
     rng = np.random.default_rng(seed)
     sw = width + ndisp
     blobs = _blur(rng.standard_normal((height, sw)), 6.0)
@@ -47,7 +49,7 @@ def make_scene_u8(height, width, ndisp, seed=0):
     tex = _blur(rng.standard_normal((height, sw)), 1.0)
     tex = tex / max(np.abs(tex).max(), 1e-12) * 64.0
     mask = _blur(rng.standard_normal((height, sw)), 10.0) > 0.0   # texture on a random half
-    scene = np.clip(blobs + np.where(mask, tex, 0.0), 0, 255).astype(np.uint8)
+    scene = np.clip(blobs + (np.where(mask, tex, 0.0) if texture else 0.0), 0, 255).astype(np.uint8)
 
     off = max(1, ndisp // 10)
     # piecewise-constant disparity over a coarse 3x3 block grid, in right-image coordinates
@@ -64,7 +66,7 @@ def make_scene_u8(height, width, ndisp, seed=0):
     return np.ascontiguousarray(left), np.ascontiguousarray(right), dmap
 
 
-def make_pair(height, width, ndisp, seed=0):
+def make_pair(height, width, ndisp, seed=0, texture=True):
     """Standardised float32 pair ([H,W,1], [H,W,1]) ready for compute_features, plus the u8 sources."""
-    left_u8, right_u8, dmap = make_scene_u8(height, width, ndisp, seed)
+    left_u8, right_u8, dmap = make_scene_u8(height, width, ndisp, seed, texture)
     return standardize(left_u8), standardize(right_u8), left_u8, right_u8, dmap

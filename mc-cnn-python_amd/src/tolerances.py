@@ -17,11 +17,15 @@ cost differences into 1e-3 .. 1e-1 px there: hence a fraction within 1e-3 px and
 FEATURES_ABS = 1e-5                 # unit feature vectors vs the float64 restatement
 FEATURES_F32_CLASS_ABS = 5e-7       # EITHER feature path (library float32 / hand-written split-operand kernels) vs a
                                     # float64 evaluation of the network by torch on the CPU, same bound for both
-# final map of the bit-exact variant (either feature path) vs the reference's final map computed from float64-
-# accumulating features: every stage behind the features is bit-exact, so this is the features' 3e-7 seen through the
-# sub-pixel parabola (SURVEY App. D asks for 99.9 % within 1e-3 px; one golden pair with near-flat cost curves reaches
-# only 98.85 % with the hand-written features and 100 % with the library's - both are within 1e-2 px everywhere)
-FEATURES_FINAL_MAP_FRAC_1E3 = 0.985
+# final map of the bit-exact variant vs the reference's final map computed from float64-accumulating features: every
+# stage behind the features is bit-exact, so this is the features' 3e-7 seen through the sub-pixel parabola.  Per
+# feature path: the library convolutions meet SURVEY App. D's end-to-end criterion (>= 99.9 % within 1e-3 px) on every
+# golden pair and are held to it; the hand-written split-operand features - the drop-in default, equally close to a
+# float64 evaluation (FEATURES_F32_CLASS_ABS) - reach 98.85 % on ONE golden pair with near-flat cost curves
+# (ref_40x48x16_s1: 1.2 % of its pixels at 1e-3 .. 4.3e-3 px) and 100 % on the others: a KNOWN DEPARTURE from App. D on
+# that fixture, stated in README.md / INTEGRATION.md "Limits"; `--features library` is the path that meets it.  Both
+# are within 1e-2 px everywhere.
+FEATURES_FINAL_MAP_FRAC_1E3 = {"miopen": 0.999, "split_f16": 0.985}
 FEATURES_FINAL_MAP_FRAC_1E2 = 0.999
 COST_VOLUME_MFMA_ABS = 2e-6         # matrix-core cost volume vs the exact one
 CBCA_SPACINGS = 8                   # separable aggregation, per iteration, in float32 spacings of max |cost|

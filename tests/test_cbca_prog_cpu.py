@@ -224,6 +224,32 @@ def test_unit_regions_are_fixed_points_after_one_iteration_including_negative_ze
     assert np.array_equal(v1[:, unit][~nan & (vol[:, unit] != 0)], vol[:, unit][~nan & (vol[:, unit] != 0)])
 
 
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 16])
+def test_skipping_from_the_second_iteration_on_equals_the_oracle(n):
+    """The schedule stereo_device.cbca_prog_pair runs, restated on the CPU checker: iteration 1 full (in -> out), every
+    later iteration leaves the unit-region pixels of its destination as they are - v1 in `out`, the ORIGINAL v0 in `in` -
+    and an even count ends with a full iteration.  With -0.0 / inf / NaN / subnormals on such pixels the final buffer
+    equals n iterations of pf:149-163 bit for bit: as an operand of another pixel's sum v0 and v1 are interchangeable."""
+    img, vol = make_case(24, 32, 6, 3)
+    unit = (support_words(img) & 0xfffff) == 0
+    assert unit.any() and not unit.all()
+    vol[:, unit] = np.resize(np.array([-0.0, 0.0, np.inf, -np.inf, np.nan, 1e-42, -1e-42, 1.5, -0.0], np.float32),
+                             vol[:, unit].shape)
+    want = vol
+    for _ in range(n):
+        want = oracle_cbca(img, want)
+    bufs = [vol.copy(), np.full_like(vol, 12345.0)]
+    for it in range(n):
+        src, dst = bufs[it % 2], bufs[1 - it % 2]
+        res = oracle_cbca(img, src)
+        skip = it >= 1 and not (n % 2 == 0 and it == n - 1)
+        if skip:
+            res[:, unit] = dst[:, unit]
+        bufs[1 - it % 2] = res
+    got = bufs[n % 2]
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_unit_region_fixed_point_for_every_kind_of_float32():
     """The arithmetic fact itself, on two million random bit patterns plus the special encodings: with aver_num = 1 the
     reference computes y = (0 + x) / 1 (pf:156-161, float32); y differs from x only for -0.0 and signalling NaNs, and

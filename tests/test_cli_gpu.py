@@ -108,6 +108,30 @@ def test_bench_launches_itself_for_several_gpus():
     assert abs(max(d["per_rank_ms_per_step"]) - d["ms_per_step"]) <= 0.01 * d["ms_per_step"] + 1e-3
 
 
+def test_bench_eight_ranks_on_the_shared_gpu():
+    """`python bench.py --gpus 8` exactly as the driver will start it on an 8-GPU node - bare, the script launches itself
+    under torch.distributed.run on 127.0.0.1 - with all eight ranks sharing the one GPU of the test box (gloo rendezvous,
+    MCCNN_BENCH_SHARED_GPU=1: RCCL refuses two ranks per device).  The launcher, the rendezvous, the barrier + gather of
+    eight times and eight device records, and the one JSON line with the whole-job rate run end to end
+    (/root/reference/src/match.py:85-91: eight independent index windows)."""
+    import json
+    env = dict(os.environ, MCCNN_BENCH_SHARED_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--config",
+           "cfg1", "--no-parity"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["process_group"] == "gloo x8"
+    assert len(d["per_rank_ms_per_step"]) == 8 and [x["rank"] for x in d["per_rank_device"]] == list(range(8))
+    assert abs(max(d["per_rank_ms_per_step"]) - d["ms_per_step"]) <= 0.01 * d["ms_per_step"] + 1e-3
+    want = 8 * 256 * 256 * 64 * 1e-6 / (d["ms_per_step"] * 1e-3)
+    assert abs(d["value"] - want) <= 0.02 * want
+
+
 def test_bench_with_library_features():
     """bench.py --library-features: the same bit-exact stages behind MIOpen's float32 convolutions; its plane-major twin
     (same features) still agrees bit for bit."""

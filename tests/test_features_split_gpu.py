@@ -128,6 +128,104 @@ def test_saturation_is_reported_by_the_kernels(nets, pf):
     assert net.split_saturated() is False                       # compute_features consumed the flag
 
 
+def test_matcher_saturation_policy_and_nan_of_either_sign(sd, nets):
+    """StereoMatcher(on_saturation=...): "fallback" (default) answers a pair whose activations left the records' range
+    with the library-feature result - through match() and through the replayed graph -, "raise" raises, "ignore" hands
+    out the clamped pair and leaves the flag to the caller.  A NaN pixel (either sign bit) sets the flag too."""
+    import synthetic
+    net = nets["converted reference checkpoint"]
+    H, W, D = 40, 56, 12
+    L, R, _, _, _ = synthetic.make_pair(H, W, D, seed=2)
+    l, r = dev(L[:, :, 0]), dev(R[:, :, 0])
+    big = l * 1e4
+    want = sd.StereoMatcher(net, features="miopen").match(big, r, D)
+    fine = sd.StereoMatcher(net, features="split_f16")
+    a = fine.match(l, r, D)
+    assert fine._library_twin is None and not net.split_saturated()          # ordinary pair: nothing repeated
+    got = fine.match(big, r, D)
+    assert fine._library_twin is not None
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    got_graph = fine.match_graph(big, r, D).clone()
+    assert torch.equal(got_graph.view(torch.int32), want.view(torch.int32))
+    assert torch.equal(fine.match_graph(l, r, D).view(torch.int32), a.view(torch.int32))
+    with pytest.raises(RuntimeError):
+        sd.StereoMatcher(net, features="split_f16", on_saturation="raise").match(big, r, D)
+    loose = sd.StereoMatcher(net, features="split_f16", on_saturation="ignore")
+    loose.match(big, r, D)
+    assert loose._library_twin is None and loose.features_saturated() and not loose.features_saturated()
+    for bits in (0x7fc00000, 0xffc00000):
+        bad = l.clone()
+        bad.view(torch.int32)[5, 7] = bits - (1 << 32) if bits >> 31 else bits
+        net.features_pair_hwc_split(bad, r)
+        assert net.split_saturated() is True, hex(bits)
+
+
+def test_extreme_contrast_eight_bit_images_and_the_saturation_fallback(sd, nets):
+    """How often does the fallback fire on 8-bit images?  match.py standardises an image ((x - mean) / std, match.py:
+    120-121), so a pixel's value is bounded by sqrt(H W) for ANY 8-bit content (a single white pixel on black), and the
+    activations follow the weights from there.  Ten kinds of extreme 8-bit pairs at 96 x 128 (|x| <= 111) and at
+    cfg2's 500 x 750 pixel count for the single-pixel image (|x| = 612): which of them trip the flag is recorded in
+    gpurun_out/parity_features_split.json; the ones that do must come back as the library-feature result."""
+    net = nets["converted reference checkpoint"]
+    rng = np.random.default_rng(0)
+    H, W, D = 96, 128, 16
+
+    def std8(img):
+        x = img.astype(np.float32)
+        return ((x - x.mean()) / max(float(x.std()), 1e-12)).astype(np.float32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    one = np.zeros((H, W), np.uint8); one[H // 2, W // 2] = 255
+    few = np.zeros((H, W), np.uint8); few[rng.integers(0, H, 12), rng.integers(0, W, 12)] = 255
+    kinds = {
+        "single white pixel on black": one,
+        "twelve white pixels on black": few,
+        "checkerboard 0/255": (((yy + xx) & 1) * 255).astype(np.uint8),
+        "vertical stripes 0/255": ((xx & 1) * 255).astype(np.uint8),
+        "half black half white": ((xx >= W // 2) * 255).astype(np.uint8),
+        "salt 0.1 % on mid grey": np.where(rng.random((H, W)) < 1e-3, 255, 128).astype(np.uint8),
+        "white noise": rng.integers(0, 256, (H, W)).astype(np.uint8),
+        "one grey level apart": np.where(rng.random((H, W)) < 0.5, 127, 128).astype(np.uint8),
+        "horizontal ramp": (xx * 255 // (W - 1)).astype(np.uint8),
+        "synthetic scene": None,
+    }
+    import synthetic
+    record = {}
+    for name, img in kinds.items():
+        if img is None:
+            Ls, Rs = synthetic.make_pair(H, W, D, seed=4)[:2]
+            l, r = dev(Ls[:, :, 0]), dev(Rs[:, :, 0])
+        else:
+            l = dev(std8(img))
+            r = dev(std8(np.roll(img, -3, axis=1)))
+        net.split_saturated()
+        net.features_pair_hwc_split(l, r)
+        fired = bool(net.split_saturated())
+        record[name] = {"largest_standardised_pixel": float(l.abs().max()), "fallback_fired": fired}
+        m = sd.StereoMatcher(net, features="split_f16")
+        got = m.match(l, r, D)
+        assert (m._library_twin is not None) == fired, name
+        if fired:
+            want = sd.StereoMatcher(net, features="miopen").match(l, r, D)
+            assert torch.equal(got.view(torch.int32), want.view(torch.int32)), name
+    # the single pixel at cfg2's pixel count: the largest value ANY 8-bit Middlebury-half image can standardise to
+    big = np.zeros((500, 750), np.uint8); big[250, 375] = 255
+    l = dev(std8(big))
+    net.features_pair_hwc_split(l, l)
+    record["single white pixel on black, 750 x 500"] = {"largest_standardised_pixel": float(l.abs().max()),
+                                                        "fallback_fired": bool(net.split_saturated())}
+    assert not record["synthetic scene"]["fallback_fired"] and not record["white noise"]["fallback_fired"]
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "parity_features_split.json")
+    old = {}
+    if os.path.isfile(path):
+        with open(path) as f:
+            old = json.load(f)
+    old["saturation_fallback_on_extreme_8bit_images"] = record
+    with open(path, "w") as f:
+        json.dump(old, f, indent=1, sort_keys=True)
+
+
 def test_split_weights_follow_weight_updates(nets):
     """The packed f16 weights are rebuilt when a weight tensor changes in place (training, set_layers)."""
     net = nets["random init"]

@@ -272,14 +272,20 @@ def test_cfg3_width_oracle_window():
     assert_bits(pf.interpolation(gdl, gdr, D), o.interpolation(odl, odr, D), "interpolation W=1242")
 
 
-@pytest.mark.parametrize("H,W,D", [(24, 750, 256), (20, 1242, 192), (12, 1500, 400)],
-                         ids=["cfg2_width_and_disparities", "cfg3_width_and_disparities", "cfg4_width_and_disparities"])
-def test_oracle_windows_at_real_width_and_disparity_range(H, W, D):
-    """The default (pixel-major, bit-exact) kernels against the CPU checker at the REAL width and the REAL disparity
-    range of cfg2 / cfg3 / cfg4 on a window of rows: cost volume written pixel-major -> CBCA x2 -> SGM_average -> CBCA
-    -> WTA (pf:78-113, 149-163, 187-235, 545-566, 245-254), every stage fed the GPU's own previous output.  750x256 is
-    one full 256-disparity chunk per wave, 1242x192 the three-disparities-per-lane kernels, 1500x400 two chunks (and
-    WTA as its own launch); the heights sit below / at the arm limit so the vertical arms clip at both borders."""
+@pytest.mark.parametrize("H,W,D,kernel", [(24, 750, 256, "prog"), (20, 1242, 192, "prog"), (12, 1500, 400, "prog"),
+                                          (20, 1242, 192, "hwd")],
+                         ids=["cfg2_width_and_disparities", "cfg3_width_and_disparities", "cfg4_width_and_disparities",
+                              "cfg3_width_cbca_hwd_fallback"])
+def test_oracle_windows_at_real_width_and_disparity_range(H, W, D, kernel):
+    """The SHIPPED default kernels against the CPU checker at the REAL width and the REAL disparity range of cfg2 / cfg3 /
+    cfg4 on a window of rows: cost volume written pixel-major -> CBCA x2 -> SGM_average -> CBCA x4 -> WTA (pf:78-113,
+    149-163, 187-235, 545-566, 245-254), every stage fed the GPU's own previous output.  The aggregation is what
+    StereoMatcher runs at these shapes: the program-driven assembly kernels (mccnn_cbca_prog_build_pair /
+    _build_skip_pair, mccnn_cbca_iter_prog_pair, and in the four-iteration aggregation two mccnn_cbca_iter_prog_pair_skip
+    launches followed by mccnn_cbca_iter_prog_pair_wta where one chunk holds D) - v4 kernels at 750x256, v3 at 1242x192,
+    v4 with two chunks (and WTA as its own launch) at 1500x400; one case keeps cbca_hwd_kernel, the fallback for images
+    wider than a program op can index (W > 2180).  The heights sit below / at the arm limit so the vertical arms clip at
+    both borders."""
     import oracle as o
     import stereo_device as sd
     import synthetic
@@ -297,7 +303,19 @@ def test_oracle_windows_at_real_width_and_disparity_range(H, W, D):
     assert_bits(cr, orr, "cost volume %dx%d (right)" % (W, D))
     # a4 x 2
     sl, sr = sd.cross_arms_pair(l, r, 0.02, 14)
-    (gl, tl), (gr, tr) = sd.cbca_hwd_pair(gl, torch.empty_like(gl), sl, gr, torch.empty_like(gr), sr, D, 2, 14)
+    words = sl.cpu().numpy().view(np.uint32).reshape(-1)[:H * W]
+    assert ((words & 0xfffff) == 0).any() and not ((words & 0xfffff) == 0).all()      # the skip launches have work to skip
+    if kernel == "prog":
+        progs = sd.cbca_prog_buffers(D, H, W, l.device)
+        assert progs is not None
+        sd.cbca_prog_build_pair(sl, sr, D, 14, progs)
+
+        def aggregate(a, ta, b, tb, n, **kw):
+            return sd.cbca_prog_pair(a, ta, sl, b, tb, sr, progs, D, n, 14, **kw)
+    else:
+        def aggregate(a, ta, b, tb, n, **kw):
+            return sd.cbca_hwd_pair(a, ta, sl, b, tb, sr, D, n, 14, **kw)
+    (gl, tl), (gr, tr) = aggregate(gl, torch.full_like(gl, float("nan")), gr, torch.full_like(gr, float("nan")), 2)
     ol, orr = o.cost_volume_aggregation(L, R, cl, cr, 0.02, 14, 2)
     cl, cr = sd.hwd_to_dhw(gl, D).cpu().numpy(), sd.hwd_to_dhw(gr, D).cpu().numpy()
     assert_bits(cl, ol, "CBCA x2 %dx%d" % (W, D))
@@ -309,15 +327,17 @@ def test_oracle_windows_at_real_width_and_disparity_range(H, W, D):
     cl, cr = sd.hwd_to_dhw(gl, D).cpu().numpy(), sd.hwd_to_dhw(gr, D).cpu().numpy()
     assert_bits(cl, ol, "SGM_average %dx%d" % (W, D))
     assert_bits(cr, orr, "SGM_average %dx%d (right)" % (W, D))
-    # a4 again (3 iterations keep the checker in seconds), the last one carrying the WTA where one chunk holds D
+    # a4 again: four iterations (full, skip, skip, full + WTA where one chunk holds D) keep the checker in seconds
     fused = D <= sd.cbca_hwd_wta_max_d()
     wl, wr = torch.empty((H, W), device="cuda"), torch.empty((H, W), device="cuda")
-    (gl, _), (gr, _) = sd.cbca_hwd_pair(gl, tl, sl, gr, tr, sr, D, 3, 14, wta_out=(wl, wr) if fused else None)
+    tl.fill_(float("nan"))
+    tr.fill_(float("nan"))
+    (gl, _), (gr, _) = aggregate(gl, tl, gr, tr, 4, wta_out=(wl, wr) if fused else None)
     if not fused:
         wl, wr = sd.wta_hwd(gl, D), sd.wta_hwd(gr, D)
-    ol, orr = o.cost_volume_aggregation(L, R, cl, cr, 0.02, 14, 3)
-    assert_bits(sd.hwd_to_dhw(gl, D).cpu().numpy(), ol, "CBCA x3 %dx%d" % (W, D))
-    assert_bits(sd.hwd_to_dhw(gr, D).cpu().numpy(), orr, "CBCA x3 %dx%d (right)" % (W, D))
+    ol, orr = o.cost_volume_aggregation(L, R, cl, cr, 0.02, 14, 4)
+    assert_bits(sd.hwd_to_dhw(gl, D).cpu().numpy(), ol, "CBCA x4 %dx%d" % (W, D))
+    assert_bits(sd.hwd_to_dhw(gr, D).cpu().numpy(), orr, "CBCA x4 %dx%d (right)" % (W, D))
     # a7
     odl, odr = o.disparity_prediction(ol, orr)
     assert_bits(wl.cpu().numpy(), odl, "WTA %dx%d" % (W, D))

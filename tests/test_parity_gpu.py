@@ -180,7 +180,8 @@ def test_golden_whole_pair_reference_order(sd, golden_cases, net_layers, feature
     """StereoMatcher.match (the timed region) with the bit-exact stage variants, fed the golden features' images, with
     either feature path: the features differ from the oracle's float64-accumulating ones by 2.4e-7 .. 4.2e-7 (both
     paths), every stage behind them is bit-exact, so the final map is compared with a flip count and the two fractions
-    of src/tolerances.py - the SAME limits for both paths.  Measured on the four golden pairs: 0 flips, every pixel
+    of src/tolerances.py - the library path held to SURVEY App. D's 99.9 % within 1e-3 px, the hand-written path to the
+    stated departure from it on one fixture.  Measured on the four golden pairs: 0 flips, every pixel
     within 1e-2 px; within 1e-3 px every pixel except on ref_40x48x16_s1, a pair with near-flat cost curves where the
     sub-pixel parabola turns 1e-7 into 1e-3 px: library features 3.5e-4 px at most, hand-written ones 1.2 % of the
     pixels at 1e-3 .. 4.3e-3 px."""
@@ -196,7 +197,7 @@ def test_golden_whole_pair_reference_order(sd, golden_cases, net_layers, feature
         close = np.isclose(out, g["bilateral"], atol=1e-3, equal_nan=True).mean()
         close2 = np.isclose(out, g["bilateral"], atol=1e-2, equal_nan=True).mean()
         assert flips <= 2, "%s: %d WTA flips" % (name, flips)
-        assert close >= tol.FEATURES_FINAL_MAP_FRAC_1E3, "%s: only %.4f of pixels within 1e-3 px" % (name, close)
+        assert close >= tol.FEATURES_FINAL_MAP_FRAC_1E3[features], "%s: only %.4f of pixels within 1e-3 px" % (name, close)
         assert close2 >= tol.FEATURES_FINAL_MAP_FRAC_1E2, "%s: only %.4f of pixels within 1e-2 px" % (name, close2)
 
 
@@ -663,15 +664,29 @@ def test_graph_replay_equals_kernel_by_kernel(sd, net_layers):
     from model import NET
     H, W, D = 64, 96, 24
     net = NET(None, input_patch_size=11, batch_size=1, device="cuda").set_layers(net_layers)
-    for cv, order, feat in ((hip.MCCNN_CV_MFMA, hip.MCCNN_CBCA_SEPARABLE, "miopen"),
-                            (hip.MCCNN_CV_MFMA, hip.MCCNN_CBCA_SEPARABLE, "split_f16"),      # what bench.py --fast --separable-cbca times
-                            (hip.MCCNN_CV_EXACT, hip.MCCNN_CBCA_REFERENCE_ORDER, "miopen")):  # pixel-major pipeline
-        m = sd.StereoMatcher(net, cv_mode=cv, cbca_order=order, features=feat)
+    for cv, order, feat, hp, kern in (
+            (hip.MCCNN_CV_MFMA, hip.MCCNN_CBCA_SEPARABLE, "miopen", None, "auto"),
+            (hip.MCCNN_CV_MFMA, hip.MCCNN_CBCA_SEPARABLE, "split_f16", None, "auto"),   # bench.py --fast --separable-cbca
+            (hip.MCCNN_CV_EXACT, hip.MCCNN_CBCA_REFERENCE_ORDER, "miopen", None, "auto"),
+            # the drop-in default and --fast: the capture holds the side stream's two stages (arms + full programs
+            # beside the cost volume, skip programs beside the first aggregation) with their event fork / join, and the
+            # saturation-flag kernels of the hand-written features
+            (hip.MCCNN_CV_EXACT, hip.MCCNN_CBCA_REFERENCE_ORDER, "split_f16", None, "auto"),
+            (hip.MCCNN_CV_MFMA, hip.MCCNN_CBCA_REFERENCE_ORDER, "split_f16", None, "auto"),
+            # fewer than three iterations in the second aggregation: no launch ever waits for the skip programs, the
+            # join at the end of the aggregation is what brings the side stream back
+            (hip.MCCNN_CV_EXACT, hip.MCCNN_CBCA_REFERENCE_ORDER, "split_f16", dict(cbca_num_iterations2=2), "auto"),
+            (hip.MCCNN_CV_EXACT, hip.MCCNN_CBCA_REFERENCE_ORDER, "split_f16", dict(cbca_num_iterations2=1), "auto"),
+            # no programs at all (cbca_hwd_kernel): the side stream carries the arms only
+            (hip.MCCNN_CV_EXACT, hip.MCCNN_CBCA_REFERENCE_ORDER, "split_f16", None, "hwd")):
+        m = sd.StereoMatcher(net, hp=hp, cv_mode=cv, cbca_order=order, features=feat, cbca_kernel=kern)
+        if kern == "hwd":
+            assert m.workspace(H, W, D)["progs"] is None
         for seed in (1, 2, 3):
             L, R, _, _, _ = synthetic.make_pair(H, W, D, seed=seed)
             l, r = dev(L[:, :, 0]), dev(R[:, :, 0])
             want = m.match(l, r, D).clone()
             got = m.match_graph(l, r, D)
             torch.cuda.synchronize()
-            assert np.array_equal(got.cpu().numpy(), want.cpu().numpy(), equal_nan=True), (cv, order, feat, seed)
+            assert np.array_equal(got.cpu().numpy(), want.cpu().numpy(), equal_nan=True), (cv, order, feat, hp, kern, seed)
         assert len(m._graphs) == 1
