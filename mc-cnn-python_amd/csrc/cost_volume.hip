@@ -178,10 +178,9 @@ __global__ __launch_bounds__(256, 3) void cost_volume_exact_pairs_kernel(const f
         const float4 v = *reinterpret_cast<const float4 *>(&sL[wl * CV_LD + c4 * 4]);
         a[c4 * 4 + 0] = v.x; a[c4 * 4 + 1] = v.y; a[c4 * 4 + 2] = v.z; a[c4 * 4 + 3] = v.w;
     }
-    constexpr int TP = 65;              // pitch of the score tile
+    constexpr int TP = CV_LD;           // pitch of the score tile: a multiple of four, so a pixel's disparities leave as float4
     float *const sT = sL;               // every thread holds its left features in registers from here on
     __syncthreads();
-    const int dl = tid & 63;
 #pragma unroll 1
     for (int d0 = 0; d0 < D && w0 + CV_TW - 1 >= d0; d0 += CV_DT) {   // beyond: every (w, d) has w < d (border fill)
         // the next tile's 64 new columns w0 - d0 - 127 .. w0 - d0 - 64 on their way (4 x 16 bytes per thread)
@@ -262,16 +261,44 @@ __global__ __launch_bounds__(256, 3) void cost_volume_exact_pairs_kernel(const f
         }
         const int nd = ((CVP_ABL & 2) && !cvp_never(D)) ? 0 : min(CV_DT, D - d0);   // disparities of this tile that exist
         const int xr0 = w0 - d0 - (CV_DT - 1);
-        // left volume: pixel w0 + px (px >= 1), disparities d0 .. d0 + nd - 1 (those with d <= w), 64 lanes = 64 disparities
-        for (int px = 1 + (tid >> 6); px < CV_TW; px += 4) {
-            const int ww = w0 + px, d = d0 + dl;
-            if (ww < W && dl < nd && ww >= d) lcv[(rowbase + ww) * (size_t)Dp + d] = sT[px * TP + dl];
+        // Both volumes leave as 16-byte stores: 16 lanes x four disparities = one pixel's 64 disparities of this tile,
+        // four pixels per wave instruction (a quarter of the store instructions of the one-float-per-lane form: the
+        // store phase is bound by their count).  A group of four that straddles an edge (w = d, the last disparity, the
+        // image border) goes out float by float.
+        const int q4 = (tid & 15) * 4, sub = tid >> 4;
+        // left volume: pixel w0 + px (px >= 1), disparities d0 .. d0 + nd - 1 (those with d <= w)
+        for (int px = 1 + sub; px < CV_TW; px += 16) {
+            const int ww = w0 + px, d = d0 + q4;
+            if (ww >= W || q4 >= nd || ww < d) continue;
+            const float4 v = *reinterpret_cast<const float4 *>(&sT[px * TP + q4]);
+            float *dst = lcv + (rowbase + ww) * (size_t)Dp + d;
+            if (q4 + 3 < nd && ww >= d + 3) {
+                *reinterpret_cast<float4 *>(dst) = v;
+            } else {
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (q4 + j < nd && ww >= d + j) dst[j] = e[j];
+            }
         }
-        // right volume: pixel x = w - d; its entries of this tile are (w = x + d, d), d0 <= d < d0 + nd
-        for (int xi = tid >> 6; xi < CV_TW + CV_DT - 1; xi += 4) {
-            const int x = xr0 + xi, d = d0 + dl, px = x + d - w0;      // tile row of w = x + d
-            if (x >= 0 && dl < nd && px >= 1 && px < CV_TW && w0 + px < W)
-                rcv[(rowbase + x) * (size_t)Dp + d] = sT[px * TP + dl];
+        // right volume: pixel x = w - d; its entries of this tile are (w = x + d, d), d0 <= d < d0 + nd: the score tile's
+        // anti-diagonals (four LDS reads per 16-byte store)
+        for (int xi = sub; xi < CV_TW + CV_DT - 1; xi += 16) {
+            const int x = xr0 + xi, d = d0 + q4, px = x + d - w0;      // tile row of w = x + d (first of the four)
+            if (x < 0 || q4 >= nd || px + 3 < 1 || px >= CV_TW) continue;
+            float *dst = rcv + (rowbase + x) * (size_t)Dp + d;
+            if (q4 + 3 < nd && px >= 1 && px + 3 < CV_TW && w0 + px + 3 < W) {
+                float4 v;
+                v.x = sT[px * TP + q4];
+                v.y = sT[(px + 1) * TP + q4 + 1];
+                v.z = sT[(px + 2) * TP + q4 + 2];
+                v.w = sT[(px + 3) * TP + q4 + 3];
+                *reinterpret_cast<float4 *>(dst) = v;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (q4 + j < nd && px + j >= 1 && px + j < CV_TW && w0 + px + j < W) dst[j] = sT[(px + j) * TP + q4 + j];
+            }
         }
         __syncthreads();                             // the score tile has been read, the ring holds the next tile's rows
     }
@@ -627,36 +654,57 @@ __global__ __launch_bounds__(64) void cost_volume_fill_hwd_lanes_kernel(float *_
     const int c_first = left ? dmax + 2 : max(W - dmax - 3, 0), nsteps = left ? c_first + 1 : W - c_first;
     auto col = [&](int t) { return left ? c_first - t : c_first + t; };
     const int voff = d < Dp ? d * 4 : kDrop;
+    const int sto = d < D ? voff : kDrop;
     float x1 = 0.f, x2 = 0.f, x3 = 0.f;
     float buf[PF];
-    // a column is fetched only while some lane of the wave still takes its score from it (columns >= the wave's smallest
-    // disparity on the left side, < W - that disparity on the right): behind that the sweep is pure recurrence
+    // Phase A: the columns from which some lane of the wave still takes its score (columns >= the wave's smallest
+    // disparity on the left side, < W - that disparity on the right): at most 66 of them.  Their loads are
+    // unconditional (a step past the last such column re-reads it, unused), so the compiler's vmcnt bookkeeping stays
+    // exact - a load inside a condition made every step wait for everything in flight, its own store included.
     const int dmin = (int)blockIdx.z * 64;
+    const int nA = min(nsteps, left ? c_first - dmin + 1 : (W - dmin) - c_first);
     auto issue = [&](int slot, int t) {
-        const int c = col(min(t, nsteps - 1));
-        if (left ? c >= dmin : c < W - dmin)       // wave-uniform
-            buf[slot] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, (unsigned)c * pix, 0));
+        const int c = col(min(t, nA - 1));
+        buf[slot] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, (unsigned)c * pix, 0));
     };
+    // s / 3.f, correctly rounded, in three operations instead of the compiler's ten: q = RN(s * RN(1/3)), one residual,
+    // one correction (division by a constant, Brisebarre / Muller).  tools/probe/div3_exhaustive.c compares it with the
+    // division for ALL 2^32 float32 inputs: identical bits (denormals, NaN payloads included) except for -0.0 and
+    // +-inf, which are handed through as they are (s / 3 = s for them).  The recurrence is a chain of 250 dependent
+    // steps per wave with four waves per SIMD: the division was most of its time.
+    auto third = [](float s) {
+        const float zh = 0.3333333432674407958984375f;            // RN(1/3) = 0x3eaaaaab
+        const float q = s * zh;
+        const float r = __builtin_fmaf(-3.0f, q, s);
+        const float q2 = __builtin_fmaf(r, zh, q);
+        return (__builtin_fabsf(s) < __builtin_inff() && s != 0.f) ? q2 : s;
+    };
+    auto step = [&](int c, bool stored, float have) {
+        float s = 0.f + x1;
+        s = s + x2;
+        s = s + x3;
+        const float val = stored ? have : third(s);
+        if (left) { x3 = x2; x2 = x1; x1 = val; }               // x1 = column c + 1 next
+        else      { x1 = x2; x2 = x3; x3 = val; }               // x3 = column c - 1 next
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rs, stored ? kDrop : sto, (unsigned)c * pix, 0);
+    };
+    if (nA > 0) {
 #pragma unroll
-    for (int k = 0; k < PF; ++k) issue(k, k);
-    for (int t0 = 0; t0 < nsteps; t0 += PF) {
+        for (int k = 0; k < PF; ++k) issue(k, k);
+        for (int t0 = 0; t0 < nA; t0 += PF) {
 #pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            const int t = t0 + k;
-            if (t >= nsteps) continue;
-            const int c = col(t);
-            const bool stored = left ? c >= d : c < W - d;         // the score itself (d >= D: pad, never used)
-            float s = 0.f + x1;
-            s = s + x2;
-            s = s + x3;
-            const float val = stored ? buf[k] : s / 3.f;
-            if (left) { x3 = x2; x2 = x1; x1 = val; }               // x1 = column c + 1 next
-            else      { x1 = x2; x2 = x3; x3 = val; }               // x3 = column c - 1 next
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rs, (!stored && d < D) ? voff : kDrop,
-                                                  (unsigned)c * pix, 0);
-            issue(k, t + PF);
+            for (int k = 0; k < PF; ++k) {
+                const int t = t0 + k;
+                if (t < nA) {
+                    const int c = col(t);
+                    step(c, left ? c >= d : c < W - d, buf[k]);     // stored: the score itself (d >= D: pad, never used)
+                }
+                issue(k, t + PF);
+            }
         }
     }
+    // Phase B: behind them the sweep is pure recurrence for every lane - no load, hence no wait: the stores just leave
+    for (int t = max(nA, 0); t < nsteps; ++t) step(col(t), false, 0.f);
 }
 
 }  // namespace mccnn

@@ -145,6 +145,7 @@ def main():
     ap.add_argument("--minvgpr", type=int, default=0); ap.add_argument("--persist", action="store_true")
     ap.add_argument("--pipe", type=int, default=0, help="the window is a program-managed ring of --w slots; widest unit")
     ap.add_argument("--ntload", action="store_true", help="non-temporal loads for rows of unit-region pixels")
+    ap.add_argument("--vpl", type=int, default=0, help="disparities per lane of the full-size run (0: the library's rule)")
     args = ap.parse_args()
     global K_DEFAULT, RING, MINVGPR, PERSIST, PIPE, NTLOAD
     K_DEFAULT, RING, MINVGPR, PERSIST, PIPE, NTLOAD = args.k, args.ring, args.minvgpr, args.persist, args.pipe, args.ntload
@@ -166,7 +167,7 @@ def main():
         sys.exit(0 if allok else 1)
     H, W, D = CONFIGS[args.config]
     Dp = sd.hwd_pitch(D)
-    vpl = 2 if Dp <= 128 else 3 if (Dp <= 192 and Dp % 3 == 0) else 4
+    vpl = args.vpl or (2 if Dp <= 128 else 3 if (Dp <= 192 and Dp % 3 == 0) else 4)
     g, path = build_hsaco(vpl, args.w, os.path.join(ROOT, "mc-cnn-python_amd", "build", "asm"), args.nb)
     mod = Module(path, g.P.name()); L = g.layout()
     Li, Ri, _, _, _ = synthetic.make_pair(H, W, D, seed=100)
