@@ -146,6 +146,8 @@ def main():
     ap.add_argument("--pipe", type=int, default=0, help="the window is a program-managed ring of --w slots; widest unit")
     ap.add_argument("--ntload", action="store_true", help="non-temporal loads for rows of unit-region pixels")
     ap.add_argument("--vpl", type=int, default=0, help="disparities per lane of the full-size run (0: the library's rule)")
+    ap.add_argument("--drop", default="", help="fl,fa: time ONLY the variant with these fractions of LOAD / ADD ops dropped "
+                                               "(counter passes under rocprofv3: every launch of the run is that variant)")
     args = ap.parse_args()
     global K_DEFAULT, RING, MINVGPR, PERSIST, PIPE, NTLOAD
     K_DEFAULT, RING, MINVGPR, PERSIST, PIPE, NTLOAD = args.k, args.ring, args.minvgpr, args.persist, args.pipe, args.ntload
@@ -187,6 +189,29 @@ def main():
     want_l = want_l.clone()
     want_r, _ = sd.cbca_hwd(c, torch.empty_like(c), sr, D, 1, 14)
     want_r = want_r.clone()
+    if args.drop:
+        fl_, fa_ = (float(x) for x in args.drop.split(","))
+        loads = set(L["loadk"]) if PIPE else set(x for row in L["load"] for x in row[1:])
+        special = loads | set(L["wait"]) | {L["end"], L["refill"]}
+        nop = L["wait"][0] | (L["M0_SRC1"] << 16)
+        ps = []
+        for pt in (pl, pr):
+            pn = pt.cpu().numpy().view(np.uint32).copy()
+            if PIPE:      # only the op words (the second words of a chunk follow its 64 ops)
+                opmask = (np.arange(pn.size).reshape(pn.shape) % 128) < 64
+            else:
+                opmask = np.ones(pn.shape, bool)
+            off = pn & 0xffff
+            isload = opmask & np.isin(off, list(loads)) & (pn != 0)
+            isadd = opmask & (pn != 0) & ~np.isin(off, list(special))
+            rng = np.random.default_rng(0)
+            pn[isload & (rng.random(pn.shape) < fl_)] = nop
+            pn[isadd & (rng.random(pn.shape) < fa_)] = nop
+            ps.append(torch.from_numpy(pn.view(np.int32)).cuda())
+        k2 = kargs([a, c], [b, d], ps, [sl, sr], Dp, H, W, nchunks, meta)
+        ms = timeit(lambda: mod.launch(grid_of(meta, nchunks * 2), k2), args.iters)
+        print("LOAD ops dropped %3.0f%%, ADD ops dropped %3.0f%%: %8.4f ms" % (100 * fl_, 100 * fa_, ms), flush=True)
+        sys.exit(0)
     ka = kargs([a, c], [b, d], [pl, pr], [sl, sr], Dp, H, W, nchunks, meta)
     b.fill_(float("nan")); d.fill_(float("nan"))
     mod.launch(grid_of(meta, nchunks * 2), ka)
