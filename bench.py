@@ -58,6 +58,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the parity block (graph replay vs eager, benchmarked variant vs the bit-exact variant)")
+    ap.add_argument("--no-bounds", action="store_true",
+                    help="skip the content-independence side measurements (the same pair without skipping, the worst-case "
+                         "scene) and the library-feature timing: under rocprofv3 every launch of a kernel then belongs to "
+                         "the benchmarked pair, so the table's averages are comparable with the line's per-launch events")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch the ~75 kernels of a pair one by one instead of replaying the captured hipGraph")
     ap.add_argument("--cpu-sample", default="auto",
@@ -357,7 +361,7 @@ def main():
     torch.cuda.synchronize()
     eager_ms = (time.perf_counter() - t1) / nside * 1e3
     lib_ms = None
-    if matcher.features != "miopen":             # the same pair with the float32 library convolutions, for reference
+    if matcher.features != "miopen" and not args.no_bounds:   # the same pair with the float32 library convolutions, for reference
         mlib = sd.StereoMatcher(net, cv_mode=matcher.cv_mode, cbca_order=matcher.cbca_order, features="miopen")
         mlib._ws = matcher._ws                   # same shape: shares the resident workspace
         mlib.match(dl, dr, D)
@@ -373,7 +377,7 @@ def main():
     # per cent of unit-region pixels, support regions of several hundred pixels almost everywhere, i.e. the reference's
     # running sums (pf:157-161) at their longest: the aggregation is then bound by its additions, not by bytes.
     noskip_ms = worst_ms = worst_unit = None
-    if matcher.pixel_major() and matcher.workspace(H, W, D)["progs"] is not None:
+    if not args.no_bounds and matcher.pixel_major() and matcher.workspace(H, W, D)["progs"] is not None:
         m2 = sd.StereoMatcher(net, cv_mode=matcher.cv_mode, cbca_order=matcher.cbca_order, features=matcher.features,
                               on_saturation="ignore", skip_unit_regions=False)
         m2._ws = matcher._ws
