@@ -516,7 +516,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // rounded region mean (up to the 2^-41 of the stored reciprocal); it differs from the reference's sequential float32
 // sum only by that sum's own rounding.  Lanes never diverge and the cost does not depend on the arm lengths.
 //
-// What a row costs, and why it is laid out this way (MI355X, measured; DESIGN.md 4.2 has the numbers):
+// What a row costs, and why it is laid out this way (MI355X, measured; docs/DESIGN_LOG_r1-r4.md 4.2 has the numbers):
 //   * LDS addresses come ready-made in the support words (namespace s4): a horizontal lookup is one AND or one shift,
 //     a vertical lookup is v_lshl_add + v_and_or (the 32-row ring wraps by mask), the reciprocal is used as stored;
 //   * prow and the ring use the column-phase layout (s4::elem): stores and the ring gathers are conflict-free by
