@@ -414,6 +414,7 @@ def main():
         "cbca_iter_pair": 2 * 2 * vol_bytes,   # one iteration on BOTH volumes (one launch: left + right)
         "cbca_iter_hwd_pair": 2 * 2 * vol_bytes,   # the same, reference-order kernel on pixel-major volumes
         "cbca_iter_prog_pair": 2 * 2 * vol_bytes,  # the same, program-driven assembly kernel (the default)
+        "cbca_iter_prog": 2 * vol_bytes,           # ... one volume per launch (two chains of launches on two streams)
         "sgm_pass": 2 * 2 * vol_bytes,    # one direction on BOTH volumes (one launch advances left + right)
         "sgm_first_pass": 2 * 2 * vol_bytes,
     }
@@ -424,7 +425,8 @@ def main():
     # on the voxels such a launch actually processes, counted from the support planes of the timed pair.
     unit_fraction = None
     algo["cbca_iter_prog_pair_skip"] = 2 * 2 * vol_bytes
-    if "cbca_iter_prog_pair_skip" in stages:
+    algo["cbca_iter_prog_skip"] = 2 * vol_bytes
+    if "cbca_iter_prog_pair_skip" in stages or "cbca_iter_prog_skip" in stages:
         ws = matcher.workspace(H, W, D)
         unit = [float(((ws[k] & 0xfffff) == 0).float().mean().item()) for k in ("sup_l", "sup_r")]
         unit_fraction = {"left": round(unit[0], 4), "right": round(unit[1], 4)}
@@ -439,21 +441,54 @@ def main():
                             "traffic_from": traffic[k]["from"] if k in traffic else None,
                             "launches_per_step": counts[k], "avg_launch_ms": round(stages[k], 4),
                             "algorithmic_bytes_per_launch": int(b)}
-    if unit_fraction is not None:
+    for skip_key, volumes in (("cbca_iter_prog_pair_skip", 2), ("cbca_iter_prog_skip", 1)):
+        if unit_fraction is None or skip_key not in rooflines:
+            continue
         # the units such a launch processes are the voxels of the pixels that are NOT fixed points: `achieved` / `frac`
-        # price those (8 B each); the nominal figure on every voxel of both volumes is kept beside them
-        r = rooflines["cbca_iter_prog_pair_skip"]
-        processed = 2 * vol_bytes * ((1.0 - unit[0]) + (1.0 - unit[1]))
+        # price those (8 B each); the nominal figure on every voxel of the launch's volume(s) is kept beside them
+        # (one-volume launches: the mean of the left and the right volume's launches)
+        r = rooflines[skip_key]
+        processed = 2 * vol_bytes * ((1.0 - unit[0]) + (1.0 - unit[1])) * (volumes / 2.0)
         r["unit_region_pixels"] = unit_fraction
         r["achieved_nominal_8B_per_voxel"], r["frac_nominal_8B_per_voxel"] = r["achieved"], r["frac"]
         r["nominal_bytes_per_launch"] = r["algorithmic_bytes_per_launch"]
         r["algorithmic_bytes_per_launch"] = r["processed_voxel_bytes_per_launch"] = int(processed)
-        r["achieved"] = round(processed / (stages["cbca_iter_prog_pair_skip"] * 1e-3) / 1e9, 1)
+        r["achieved"] = round(processed / (stages[skip_key] * 1e-3) / 1e9, 1)
         r["frac"] = r["frac_on_processed_voxels"] = round(r["achieved"] / HBM_PEAK_GBS, 4)
         r["note"] = ("second and later iterations of an aggregation (not the last, which carries the WTA): pixels whose support region is the pixel itself are "
                      "fixed points and are neither read for their own sake nor written (same bits); algorithmic bytes = "
                      "8 B x the voxels of the OTHER pixels (the units this launch processes), `frac_nominal_8B_per_voxel` "
-                     "prices every voxel of both volumes as SURVEY 8d words it, `traffic` = the HBM bytes rocprofv3 counted")
+                     "prices every voxel of the launch as SURVEY 8d words it, `traffic` = the HBM bytes rocprofv3 counted")
+    # One-volume launches run as two concurrent chains (left volume on the main stream, right volume on a second one):
+    # a launch's duration - by the events on its own stream, and in rocprofv3's table - is its duration WHILE ITS TWIN
+    # RUNS, so the per-launch figure is that of a kernel with half of the chip; the aggregation as a stage is priced
+    # from the bracket around the whole stage below (`aggregation_stages`).
+    for k in ("cbca_iter_prog", "cbca_iter_prog_skip"):
+        if k in rooflines:
+            rooflines[k]["concurrent_launches"] = 2
+            rooflines[k]["frac_x_concurrent_launches"] = round(2 * rooflines[k]["frac"], 4)
+            rooflines[k]["concurrency_note"] = ("two launches of this kernel run at the same time (one per volume, two "
+                                                "streams): `avg_launch_ms` is a launch's duration beside its twin")
+    agg_stages = {}
+    spans = {k: float(np.mean(v)) for k, v in timer.spans_ms().items()}
+    hp_ = matcher.hp
+    for name, n_it in (("aggregation_1", int(hp_["cbca_num_iterations1"])), ("aggregation_2", int(hp_["cbca_num_iterations2"]))):
+        if name in spans and n_it > 0:
+            # stereo_device.cbca_prog_pair's rule for which iterations leave the unit-region pixels alone
+            fuse = name == "aggregation_2" and D <= sd.cbca_hwd_wta_max_d()
+            n_skip = 0
+            if unit_fraction is not None and matcher.skip_unit_regions:
+                n_skip = sum(1 for it in range(n_it)
+                             if it >= 1 and not (fuse and it == n_it - 1) and not (n_it % 2 == 0 and it == n_it - 1))
+            proc = (n_it - n_skip) * 4 * vol_bytes
+            if n_skip:
+                proc += n_skip * 2 * vol_bytes * ((1.0 - unit[0]) + (1.0 - unit[1]))
+            t = spans[name] * 1e-3
+            agg_stages[name] = {"ms": round(spans[name], 4), "iterations": n_it, "skip_iterations": n_skip,
+                                "ms_per_iteration": round(spans[name] / n_it, 4),
+                                "processed_voxel_bytes": int(proc), "achieved_GBs": round(proc / t / 1e9, 1),
+                                "frac_of_hbm_peak": round(proc / t / 1e9 / HBM_PEAK_GBS, 4),
+                                "nominal_frac_8B_per_voxel": round(n_it * 4 * vol_bytes / t / 1e9 / HBM_PEAK_GBS, 4)}
     # the conv stack on the matrix cores (north_star: MFMA utilisation against the MI355X peak): algorithmic float32
     # FLOPs of model.py:51-64 on both padded images (296 kFLOP per pixel and image) over the stage's time,
     # against the dense f16 matrix peak - and what the kernels ISSUE: every multiply of layers 2..5 as three f16 products
@@ -519,6 +554,9 @@ def main():
                    "weights": "converted reference checkpoint" if os.path.isfile(wpath) else "random init"},
         "roofline": dict(rooflines[dominant], kernel=dominant) if dominant else None,
         "rooflines": rooflines,
+        # the two aggregations as stages (brackets around all their launches, both streams joined): what the chains of
+        # concurrent one-volume launches achieve together
+        "aggregation_stages": agg_stages,
         "sgm_stage": {"ms": round(sgm_stage_ms, 4), "algorithmic_bytes": int(4 * 2 * 2 * vol_bytes),
                       "achieved_GBs": round(4 * 2 * 2 * vol_bytes / (sgm_stage_ms * 1e-3) / 1e9, 1) if sgm_stage_ms else None,
                       "frac_of_hbm_peak": round(4 * 2 * 2 * vol_bytes / (sgm_stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)

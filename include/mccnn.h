@@ -45,7 +45,7 @@ extern "C" {
 
 typedef void *mccnn_stream_t; /* hipStream_t */
 
-#define MCCNN_ABI_VERSION 5 /* 2: window-mask plane, *_hwd entry points; 3: saturation flags; 4: program-driven CBCA; 5: skip programs */
+#define MCCNN_ABI_VERSION 6 /* 2: window-mask plane, *_hwd entry points; 3: saturation flags; 4: program-driven CBCA; 5: skip programs; 6: one-volume launches */
 
 #define MCCNN_E_INVALID (-1)     /* bad argument (null pointer, non-positive size, unsupported shape) */
 #define MCCNN_E_UNSUPPORTED (-2) /* shape outside what the kernels were built for (e.g. D > 512 for SGM) */
@@ -214,6 +214,17 @@ int mccnn_cbca_iter_prog_pair_skip(const float *in_left, float *out_left, const 
                                    const void *prog_left, const float *in_right, float *out_right,
                                    const mccnn_support_t *support_right, const void *prog_right, int D, int H, int W,
                                    int L, mccnn_stream_t stream);
+
+/* One volume per launch (round 5): the same kernels with half the grid.  A stereo pair's two volumes are independent
+ * chains of iterations; issued as two such chains on two streams, one chain's launch fills the compute units that the
+ * other chain's launch leaves idle while its last and heaviest patches finish (the skip launches, whose work sits in a
+ * few image regions, end with most of the chip idle): 8.7 % less time for 16 iterations at 750x500x256 than one
+ * two-volume launch per iteration, same bits.  `prog` is one image's buffer as mccnn_cbca_prog_build_pair /
+ * _build_skip_pair wrote it (either position of the pair); the same refusals as the two-volume entry points. */
+int mccnn_cbca_iter_prog(const float *in, float *out, const mccnn_support_t *support, const void *prog, int D, int H, int W,
+                         int L, mccnn_stream_t stream);
+int mccnn_cbca_iter_prog_skip(const float *in, float *out, const mccnn_support_t *support, const void *prog, int D, int H,
+                              int W, int L, mccnn_stream_t stream);
 
 /* ---- layout changes between DHW and HWD ------------------------------------------------------------------- */
 int mccnn_hwd_pitch(int D); /* Dp: D rounded up to a multiple of 4 (16-byte rows) */

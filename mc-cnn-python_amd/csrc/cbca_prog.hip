@@ -323,16 +323,21 @@ extern "C" int mccnn_cbca_prog_build_skip_pair(const mccnn_support_t *support_le
 static int prog_iter(const char *who, const float *in_left, float *out_left, const mccnn_support_t *support_left,
                      const void *prog_left, const float *in_right, float *out_right, const mccnn_support_t *support_right,
                      const void *prog_right, int D, int H, int W, int L, float *disp_left, float *disp_right,
-                     int store_right, bool wta, bool skip_unit, mccnn_stream_t stream)
+                     int store_right, bool wta, bool skip_unit, mccnn_stream_t stream, bool single = false)
 {
     using namespace mccnn;
+    if (single) {       // one volume per launch: the launch has no second job, its slots repeat the first one's
+        in_right = in_left;
+        support_right = support_left;
+        prog_right = prog_left;
+    }
     MCCNN_REQUIRE(in_left && out_left && support_left && prog_left && in_right && support_right && prog_right,
                   MCCNN_E_INVALID, "%s: null pointer", who);
-    MCCNN_REQUIRE(out_right || (wta && !store_right), MCCNN_E_INVALID, "%s: out_right is null", who);
+    MCCNN_REQUIRE(single || out_right || (wta && !store_right), MCCNN_E_INVALID, "%s: out_right is null", who);
     MCCNN_REQUIRE(!wta || (disp_left && disp_right), MCCNN_E_INVALID, "%s: null disparity map", who);
-    if (!out_right) out_right = out_left;     // never dereferenced: the kernel gets an empty descriptor for it
-    MCCNN_REQUIRE(in_left != out_left && in_right != out_right && (out_left != out_right || !store_right) &&
-                      in_left != out_right && in_right != out_left,
+    if (!out_right || single) out_right = out_left;     // never dereferenced: an empty descriptor / no second job
+    MCCNN_REQUIRE(in_left != out_left && (single || (in_right != out_right && (out_left != out_right || !store_right) &&
+                                                     in_left != out_right && in_right != out_left)),
                   MCCNN_E_INVALID, "%s: outputs must not alias an input or each other", who);
     MCCNN_REQUIRE(L >= 1 && L <= 14, MCCNN_E_UNSUPPORTED, "%s: L=%d outside [1,14]", who, L);
     prog::Shape s;
@@ -368,7 +373,7 @@ static int prog_iter(const char *who, const float *in_left, float *out_left, con
     static_assert(sizeof(args) == 0x80, "kernarg layout of csrc/asm/cbca_prog_gen.py");
     size_t size = wta ? 0x80 : 0x60;
     void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-    const hipError_t e = hipModuleLaunchKernel(fn, 8 * s.band_groups, s.ngroups, s.nchunks * 2, 64, 1, 1, 0,
+    const hipError_t e = hipModuleLaunchKernel(fn, 8 * s.band_groups, s.ngroups, s.nchunks * (single ? 1 : 2), 64, 1, 1, 0,
                                                (hipStream_t)stream, nullptr, extra);
     MCCNN_REQUIRE(e == hipSuccess, (int)e, "%s: %s", who, hipGetErrorString(e));
     return 0;
@@ -390,6 +395,20 @@ extern "C" int mccnn_cbca_iter_prog_pair_skip(const float *in_left, float *out_l
 {
     return prog_iter("mccnn_cbca_iter_prog_pair_skip", in_left, out_left, support_left, prog_left, in_right, out_right,
                      support_right, prog_right, D, H, W, L, nullptr, nullptr, 1, false, true, stream);
+}
+
+extern "C" int mccnn_cbca_iter_prog(const float *in, float *out, const mccnn_support_t *support, const void *prog, int D,
+                                    int H, int W, int L, mccnn_stream_t stream)
+{
+    return prog_iter("mccnn_cbca_iter_prog", in, out, support, prog, nullptr, nullptr, nullptr, nullptr, D, H, W, L, nullptr,
+                     nullptr, 1, false, false, stream, true);
+}
+
+extern "C" int mccnn_cbca_iter_prog_skip(const float *in, float *out, const mccnn_support_t *support, const void *prog,
+                                         int D, int H, int W, int L, mccnn_stream_t stream)
+{
+    return prog_iter("mccnn_cbca_iter_prog_skip", in, out, support, prog, nullptr, nullptr, nullptr, nullptr, D, H, W, L,
+                     nullptr, nullptr, 1, false, true, stream, true);
 }
 
 extern "C" int mccnn_cbca_iter_prog_pair_wta(const float *in_left, float *out_left, const mccnn_support_t *support_left,

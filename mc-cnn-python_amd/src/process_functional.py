@@ -136,7 +136,8 @@ def cost_volume_aggregation(left_image, right_image, left_cost_volume, right_cos
                                     "both" if int(max_average_time) > 2 else "full")
             hl, hr = sd.dhw_to_hwd(vl), sd.dhw_to_hwd(vr)       # copies: the caller's arrays stay as they are
             (rl, _), (rr, _) = sd.cbca_prog_pair(hl, torch.empty_like(hl), supports[0], hr, torch.empty_like(hr),
-                                                 supports[1], progs, D, int(max_average_time), int(distance_threshold))
+                                                 supports[1], progs, D, int(max_average_time), int(distance_threshold),
+                                                 right_stream=sd.right_stream(hl.device))
             return _ret(sd.hwd_to_dhw(rl, D), was_np), _ret(sd.hwd_to_dhw(rr, D), was_np)
     for k, vol in enumerate((left_cost_volume, right_cost_volume)):
         v, was_np = _dev(vol)

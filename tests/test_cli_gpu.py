@@ -141,12 +141,12 @@ def test_bench_with_library_features():
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     d = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
-    assert d["roofline"]["kernel"] in ("cbca_iter_prog_pair", "cbca_iter_prog_pair_skip") and "MIOpen" in d["config"]["features"]
+    assert d["roofline"]["kernel"] in ("cbca_iter_prog_pair", "cbca_iter_prog_pair_skip", "cbca_iter_prog", "cbca_iter_prog_skip") and "MIOpen" in d["config"]["features"]
     assert d["parity"]["timed_path_equals_kernel_by_kernel"] and d["parity"]["final_map_bit_identical"]
     assert d["parity_violations"] == [] and d["dtype"] == "f32"
 
 
-@pytest.mark.parametrize("extra,kernels", [([], ("cbca_iter_prog_pair", "cbca_iter_prog_pair_skip")),
+@pytest.mark.parametrize("extra,kernels", [([], ("cbca_iter_prog_pair", "cbca_iter_prog_pair_skip", "cbca_iter_prog", "cbca_iter_prog_skip")),
                                            (["--separable-cbca"], ("cbca_iter_pair",))],
                          ids=["matrix_core_cost_volume", "and_separable_aggregation"])
 def test_bench_fast_variant_states_and_meets_its_tolerance(extra, kernels):
@@ -182,7 +182,7 @@ def test_bench_world_size_one_through_rccl():
     assert d["process_group"] == "nccl x1", d["process_group"]
     assert d["n_gpus"] == 1 and d["config"]["launch"] == "one hipGraph replay per pair"
     # the benchmarked variant is the drop-in default: float32, bit-exact, its twin agrees bit for bit
-    assert d["roofline"]["kernel"] in ("cbca_iter_prog_pair", "cbca_iter_prog_pair_skip") and 0.0 < d["roofline"]["frac"] < 1.5
+    assert d["roofline"]["kernel"] in ("cbca_iter_prog_pair", "cbca_iter_prog_pair_skip", "cbca_iter_prog", "cbca_iter_prog_skip") and 0.0 < d["roofline"]["frac"] < 1.5
     assert d["dtype"] == "f32" and d["config"]["variant"].startswith("bit-exact")
     assert d["config"]["features"].startswith("hand-written matrix-core")
     assert d["parity"]["final_map_bit_identical"] and d["parity"]["timed_path_equals_kernel_by_kernel"]

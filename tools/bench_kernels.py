@@ -91,7 +91,8 @@ def main():
                       "mccnn_sgm_first_pass")
         add("sgm_first_pass", first_pass, 4 * vol_bytes)
     # the pixel-major kernels of the bit-exact variant (two-volume launches like the pair runs them)
-    if not only or only & {"cbca_iter_hwd", "cbca_iter_hwd_pair", "wta_hwd", "cbca_iter_prog_pair", "cbca_iter_prog_pair_skip", "cbca_prog_build"}:
+    if not only or only & {"cbca_iter_hwd", "cbca_iter_hwd_pair", "wta_hwd", "cbca_iter_prog_pair", "cbca_iter_prog_pair_skip",
+                           "cbca_prog_build", "cbca_iter_prog", "cbca_iter_prog_skip"}:
         hb, hb2 = torch.empty_like(hwd), torch.empty_like(hwd2)
         add("cbca_iter_hwd", lambda: sd.cbca_hwd(hwd, hb, sup, D, 1, 14), 2 * vol_bytes)
         add("cbca_iter_hwd_pair", lambda: sd.cbca_hwd_pair(hwd, hb, sup, hwd2, hb2, sup2, D, 1, 14), 4 * vol_bytes)
@@ -106,6 +107,13 @@ def main():
                     hip.ptr(hwd), hip.ptr(hb), hip.ptr(sup), hip.ptr(progs[0]), hip.ptr(hwd2), hip.ptr(hb2), hip.ptr(sup2),
                     hip.ptr(progs[1]), D, H, W, 14, hip.stream()), "mccnn_cbca_iter_prog_pair_skip")
             add("cbca_iter_prog_pair_skip", skip_iteration, 4 * vol_bytes)
+            lib = hip.load()        # one volume per launch (what StereoMatcher issues as two chains on two streams), alone
+            add("cbca_iter_prog", lambda: hip.check(lib.mccnn_cbca_iter_prog(
+                hip.ptr(hwd), hip.ptr(hb), hip.ptr(sup), hip.ptr(progs[0]), D, H, W, 14, hip.stream()), "mccnn_cbca_iter_prog"),
+                2 * vol_bytes)
+            add("cbca_iter_prog_skip", lambda: hip.check(lib.mccnn_cbca_iter_prog_skip(
+                hip.ptr(hwd), hip.ptr(hb), hip.ptr(sup), hip.ptr(progs[0]), D, H, W, 14, hip.stream()), "mccnn_cbca_iter_prog_skip"),
+                2 * vol_bytes)
         add("wta_hwd", lambda: sd.wta_hwd(hwd, D), vol_bytes)
         del hb, hb2
     add("dhw_to_hwd", lambda: sd.dhw_to_hwd(va, hwd), 2 * vol_bytes)

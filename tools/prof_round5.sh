@@ -8,6 +8,8 @@ if [ "$PART" = 1 ]; then
   cd $R
   SETS="1 2 3 4 5 6" timeout 400 bash tools/pmc_kernel.sh cbca_iter_prog_pair mccnn_cbca_prog_v4 > $O/pmc_cbca_prog.txt 2>&1
   SETS="1 2 3 4 5" timeout 400 bash tools/pmc_kernel.sh cbca_iter_prog_pair_skip mccnn_cbca_prog_v4_skip > $O/pmc_cbca_prog_skip.txt 2>&1
+  SETS="3 4 5" timeout 300 bash tools/pmc_kernel.sh cbca_iter_prog mccnn_cbca_prog_v4 > $O/pmc_cbca_prog_one_volume.txt 2>&1
+  SETS="3 4 5" timeout 300 bash tools/pmc_kernel.sh cbca_iter_prog_skip mccnn_cbca_prog_v4_skip > $O/pmc_cbca_prog_skip_one_volume.txt 2>&1
   SETS="3 4 5" timeout 300 bash tools/pmc_kernel.sh sgm_pass_h sgm_pass_kernel > $O/pmc_sgm_pass.txt 2>&1
   SETS="4 5" timeout 200 bash tools/pmc_kernel.sh sgm_first_pass sgm_first_pass_kernel > $O/pmc_sgm_first_pass.txt 2>&1
   SETS="4 5" timeout 200 bash tools/pmc_kernel.sh cbca_iter_hwd_pair cbca_hwd_kernel > $O/pmc_cbca_hwd.txt 2>&1
