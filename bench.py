@@ -465,10 +465,21 @@ def main():
     # from the bracket around the whole stage below (`aggregation_stages`).
     for k in ("cbca_iter_prog", "cbca_iter_prog_skip"):
         if k in rooflines:
-            rooflines[k]["concurrent_launches"] = 2
-            rooflines[k]["frac_x_concurrent_launches"] = round(2 * rooflines[k]["frac"], 4)
-            rooflines[k]["concurrency_note"] = ("two launches of this kernel run at the same time (one per volume, two "
-                                                "streams): `avg_launch_ms` is a launch's duration beside its twin")
+            r = rooflines[k]
+            r["concurrent_launches"] = 2
+            r["achieved_one_launch"], r["frac_one_launch"] = r["achieved"], r["frac"]
+            r["achieved"], r["frac"] = round(2 * r["achieved"], 1), round(2 * r["frac"], 4)
+            for kk in ("achieved_nominal_8B_per_voxel", "frac_nominal_8B_per_voxel"):
+                if kk in r:
+                    r[kk + "_one_launch"] = r[kk]
+                    r[kk] = round(2 * r[kk], 4 if kk.startswith("frac") else 1)
+            r["frac_on_processed_voxels"] = r["frac"] if "frac_on_processed_voxels" in r else None
+            r["concurrency_note"] = ("TWO launches of this kernel run at the same time, one per volume on two streams: "
+                                     "`avg_launch_ms` is one launch's duration beside its twin (rocprofv3's table shows the "
+                                     "same), `algorithmic_bytes_per_launch` one launch's bytes; `achieved` / `frac` are "
+                                     "what the two concurrent launches move together (2 x bytes / avg_launch_ms), "
+                                     "`*_one_launch` the same for a single launch; `aggregation_stages` prices the whole "
+                                     "stage from a bracket around it and agrees")
     agg_stages = {}
     spans = {k: float(np.mean(v)) for k, v in timer.spans_ms().items()}
     hp_ = matcher.hp

@@ -103,6 +103,11 @@ def _is_literal(x):
     return False
 
 
+def _is_label_diff(x):
+    """An assemble-time constant `labelA-labelB` (a 32-bit literal in the encoding)."""
+    return isinstance(x, str) and re.match(r"^[A-Za-z_]\w*-[A-Za-z_]\w*$", x) is not None
+
+
 def ins_size(i):
     """Encoded size in bytes (checked against llvm-objdump by the build, see check_layout)."""
     if i.op == "label" or i.op.startswith("pseudo_"):
@@ -115,17 +120,25 @@ def ins_size(i):
         return 8
     if i.op == "s_set_gpr_idx_on":
         return 4
-    return 8 if any(_is_literal(a) or (isinstance(a, str) and "code_base" in a) for a in i.args) else 4
+    return 8 if any(_is_literal(a) or _is_label_diff(a) for a in i.args) else 4
 
 
 class Params:
     def __init__(self, vpl=4, K=2, G=5, W=12, NB=1, PF=0, wta=False, debug=0, order=0, minvgpr=0, skip=False, ring=0, persist=False,
-                 pipe=0, ntload=False):
+                 pipe=0, ntload=False, early=False):
         assert K in (1, 2, 4, 8), "anchor sets are aligned power-of-two groups of anchor rows"
         # ntload: a second LOAD line (n <= G) whose loads carry the non-temporal hint: for region rows that consist of
         # unit-region pixels only (nobody else's region holds them, so keeping them in L2 only evicts lines that
         # neighbouring patches will read again)
         self.ntload = ntload
+        # early (round 5, experimental: measured 1.5-2.5 % SLOWER on all four kernels, profiles/r05_cbca_prog_early.txt;
+        # off by default): the first op of a program - its first LOAD, or END when the program is empty - is fetched by a
+        # scalar load beside the vector load of the program's first 64 ops and dispatched as soon as it is there: the
+        # first window is requested while the rest of the program is still on its way (a wave no longer waits for its
+        # program AND THEN for its first window), and the wave of an empty skip program ends without waiting for
+        # anything but that one word.  The first LOAD runs on a copy of the load line whose dispatcher waits BEFORE it
+        # reads the next op out of the program register.
+        self.early = bool(early) and not (pipe or ring or persist or NB != 1)
         assert K * G <= 20, "the region sizes of the K x G anchors live in s[16:35]"
         self.VPL, self.K, self.G, self.W, self.NB, self.PF, self.wta, self.debug = vpl, K, G, W, NB, PF, wta, debug
         self.order = order                          # 0: column-group-major dispatch inside an XCD's band, 1: row-group-major
@@ -498,6 +511,8 @@ class Gen:
             e("buffer_load_dword", vreg(P.v_progA), vreg(P.v_lane4), s("rs_prog", 4), 0, offen=True)
             e("buffer_load_dword", vreg(P.v_progB), vreg(P.v_lane4), s("rs_prog", 4), 0, offen=True, offset=256)
             e("s_movk_i32", s("progoff"), 512)
+            if P.early:
+                e("s_load_dword", s("op"), s("rs_prog", 2), 0, comment="the program's first op (descriptor words 0-1 = its address)")
         if P.ring:
             e("v_lshlrev_b32", vreg(P.v_lane16), 4, "v0", comment="lane * 16: this lane's bytes of an LDS slot")
             e("s_mov_b32", s("ring_head"), 0)
@@ -553,9 +568,23 @@ class Gen:
         e("s_addc_u32", sreg(S["base"] + 1), sreg(S["base"] + 1), 0)
         e("s_mov_b32", s("i"), 0)
         e("s_mov_b32", s("safe_m0"), M0_SRC1)
-        e("s_waitcnt", "vmcnt(0)")
-        e("s_set_gpr_idx_on", s("i"), "gpr_idx(SRC1)", comment="index mode on for the whole program: M0 = 0x2000 | idx")
-        self.tail()
+        if not P.early:
+            e("s_waitcnt", "vmcnt(0)")
+            e("s_set_gpr_idx_on", s("i"), "gpr_idx(SRC1)", comment="index mode on for the whole program: M0 = 0x2000 | idx")
+            self.tail()
+        else:
+            e("s_set_gpr_idx_on", s("i"), "gpr_idx(SRC1)", comment="index mode on for the whole program: M0 = 0x2000 | idx")
+            e("s_mov_b32", s("i"), 1, comment="op 0 comes from the scalar load, the dispatchers go on with op 1")
+            e("s_waitcnt", "lgkmcnt(0)")
+            e("s_sext_i32_i16", s("t"), s("op"))
+            e("s_cmp_eq_u32", s("t"), "h_end-code_base")
+            e("s_cbranch_scc1", "first_is_end")
+            e("s_add_u32", s("t"), s("t"), "h_loadf1-h_load1", comment="the same LOAD on the first-load copy of the line")
+            self.label("first_is_end")
+            e("s_lshr_b32", "m0", s("op"), 16)
+            e("s_add_u32", s("pc"), s("base"), s("t"))
+            e("s_addc_u32", sreg(S["pc"] + 1), sreg(S["base"] + 1), 0)
+            e("s_setpc_b64", s("pc", 2))
 
     def handlers(self):
         P, e = self.P, self.e
@@ -611,6 +640,8 @@ class Gen:
             self.tail()
         for b in range(0 if P.pipe else P.NB):
             for n in range(1, W + 1):
+                if b == 0 and n == 1:
+                    self.label("h_load1")
                 self.label("load_b%d_n%d" % (b, n))
                 e("s_mul_i32", s("so"), "m0", s("pix"))
                 e("s_mov_b32", "m0", s("safe_m0"))
@@ -622,6 +653,22 @@ class Gen:
                 if n > 1:
                     e("s_sub_u32", s("so"), s("so"), s("pix"))
             self.tail(wait="vmcnt(0)" if P.NB == 1 else None)
+        if P.early:
+            # the first LOAD of a program (dispatched by the prologue, see Params.early): same stubs at the same spacing,
+            # same line; its dispatcher waits first - the program register it reads op 1 from may still be in flight
+            for n in range(1, W + 1):
+                self.label("h_loadf1" if n == 1 else "loadf_n%d" % n)
+                e("s_mul_i32", s("so"), "m0", s("pix"))
+                e("s_mov_b32", "m0", s("safe_m0"))
+                if n != W:
+                    e("s_branch", "loadf_blk%d" % n)
+            for n in range(W, 0, -1):
+                self.label("loadf_blk%d" % n)
+                self.vload(P.PHYS_WIN + P.RS * (n - 1), P.v_voff, S["rs_in"], s("so"))
+                if n > 1:
+                    e("s_sub_u32", s("so"), s("so"), s("pix"))
+            e("s_waitcnt", "vmcnt(0)")
+            self.tail()
         if P.ntload and not P.pipe:
             for n in range(1, G + 1):
                 self.label("loadnt_n%d" % n)
@@ -702,6 +749,7 @@ class Gen:
         K, G, VPL, W = P.K, P.G, P.VPL, P.W
         s = lambda n, c=1: sreg(S[n], c) if isinstance(n, str) else sreg(n, c)
         # ---- END: pf:161 -------------------------------------------------------------------------------------------------------
+        self.label("h_end")
         self.label("end")
         e("s_set_gpr_idx_off")
         if P.persist:     # the next patch of this wave: its program travels under the divisions and the stores
@@ -963,7 +1011,7 @@ class Gen:
             else:
                 line = i.render()
                 # local labels: branch targets and the code_base difference
-                line = re.sub(r"\b(code_base|after_getpc|done|pf_done|pf_loop\d+|load_b\d+_blk\d+|loadblk_\d+|loadnt_blk\d+|load_done|nodiv_\d+_\d+|nostore_\d+_\d+|pf_blk\d+|cp_blk\d+|p_div|p_divd|p_z|p_patch|p_nextz|e_nofetch)\b", lambda m: ".L%s_%s" % (name, m.group(1)), line)
+                line = re.sub(r"\b(code_base|after_getpc|done|pf_done|pf_loop\d+|load_b\d+_blk\d+|loadblk_\d+|loadnt_blk\d+|load_done|loadf_blk\d+|h_end|h_load1|h_loadf1|first_is_end|nodiv_\d+_\d+|nostore_\d+_\d+|pf_blk\d+|cp_blk\d+|p_div|p_divd|p_z|p_patch|p_nextz|e_nofetch)\b", lambda m: ".L%s_%s" % (name, m.group(1)), line)
                 out.append(line)
         kargs = 0x80 if (P.wta or P.persist) else 0x60
         out += [".Lfunc_end_%s:" % name, ".size %s, .Lfunc_end_%s-%s" % (name, name, name), "",
@@ -1030,11 +1078,12 @@ def main():
     ap.add_argument("--skip", action="store_true", help="the kernel of the skip programs (unit regions neither divided nor stored)")
     ap.add_argument("--minvgpr", type=int, default=0, help="experiments: allocate at least this many VGPRs (occupancy)")
     ap.add_argument("--ntload", action="store_true", help="non-temporal loads for region rows of unit-region pixels")
+    ap.add_argument("--early", action="store_true", help="experimental: the program's first op dispatched from a scalar load")
     ap.add_argument("--pipe", type=int, default=0, help="the window is a program-managed ring of --w slots; the widest unit")
     ap.add_argument("-o", default=None)
     ap.add_argument("--header", default=None)
     a = ap.parse_args()
-    P = Params(vpl=a.vpl, K=a.k, W=a.w, NB=a.nb, PF=a.pf, wta=a.wta, order=a.order, minvgpr=a.minvgpr, skip=a.skip, ring=a.ring, persist=a.persist, pipe=a.pipe, ntload=a.ntload)
+    P = Params(vpl=a.vpl, K=a.k, W=a.w, NB=a.nb, PF=a.pf, wta=a.wta, order=a.order, minvgpr=a.minvgpr, skip=a.skip, ring=a.ring, persist=a.persist, pipe=a.pipe, ntload=a.ntload, early=a.early)
     g = Gen(P).build()
     if a.o:
         open(a.o, "w").write(g.render())

@@ -111,7 +111,7 @@ class Wave:
         m = _RE_S.match(x)
         if m:
             return self.s[int(m.group(1))]
-        if "code_base" in x:
+        if re.match(r"^[A-Za-z_]\w*-[A-Za-z_]\w*$", x):          # an assemble-time label difference
             a, b = x.split("-")
             return (self.label_off[a] - self.label_off[b]) & MASK32
         raise SimError("scalar source %r" % (x,))

@@ -268,6 +268,23 @@ def test_unit_region_fixed_point_for_every_kind_of_float32():
     assert np.all((bits[changed] == 0x80000000) | (np.isnan(x[changed]) & (y.view(np.uint32)[changed] == quiet[changed])))
 
 
+@pytest.mark.parametrize("skip", [False, True])
+def test_generated_kernel_with_early_first_op_in_the_simulator(skip):
+    """Params(early=True) (experimental, measured slower, off by default): the program's first op from a scalar load, the
+    first LOAD on its own copy of the line - and an empty skip program ends on that one word."""
+    g = gen.Gen(gen.Params(vpl=4, K=4, W=20, early=True, skip=skip)).build()
+    L = g.layout()
+    img, vol0 = make_case(24, 32, 8, 3)
+    if not skip:
+        got, _ = simulate(g, L, img, vol0)
+        assert np.array_equal(got, oracle_cbca(img, vol0))
+    else:
+        v1 = oracle_cbca(img, vol0)
+        v2 = oracle_cbca(img, v1)
+        got, _ = simulate(g, L, img, v2, out_init=v1)
+        assert np.array_equal(got, oracle_cbca(img, v2), equal_nan=True)
+
+
 def test_generated_kernel_with_scalar_prefetch_in_the_simulator():
     """The L2 warm-up loads never leave the volume (the simulator faults on any access outside an allocation)."""
     for (H, W, D, pf) in ((12, 17, 8, 5), (9, 33, 4, 20), (11, 16, 6, 10)):

@@ -31,13 +31,14 @@ MINVGPR = 0
 PERSIST = False
 PIPE = 0
 NTLOAD = False
+EARLY = False
 
 
 def build_hsaco(vpl, w, outdir, nb=1, debug=0, pf=0, k=None):
     k = k or K_DEFAULT
     os.makedirs(outdir, exist_ok=True)
-    g = gen.Gen(gen.Params(vpl=vpl, K=k, W=w, NB=nb, debug=debug, PF=pf, ring=RING, minvgpr=MINVGPR, persist=PERSIST, pipe=PIPE, ntload=NTLOAD)).build()
-    base = os.path.join(outdir, "cbca_prog_v%d_k%d_w%d_b%d_g%d_p%d_r%d_m%d_s%d_q%d_n%d" % (vpl, k, w, nb, debug, pf, RING, MINVGPR, int(PERSIST), PIPE, int(NTLOAD)))
+    g = gen.Gen(gen.Params(vpl=vpl, K=k, W=w, NB=nb, debug=debug, PF=pf, ring=RING, minvgpr=MINVGPR, persist=PERSIST, pipe=PIPE, ntload=NTLOAD, early=EARLY)).build()
+    base = os.path.join(outdir, "cbca_prog_v%d_k%d_w%d_b%d_g%d_p%d_r%d_m%d_s%d_q%d_n%d_e%d" % (vpl, k, w, nb, debug, pf, RING, MINVGPR, int(PERSIST), PIPE, int(NTLOAD), int(EARLY)))
     if not os.path.exists(base + ".hsaco") or os.path.getmtime(base + ".hsaco") < os.path.getmtime(gen.__file__):
         open(base + ".s", "w").write(g.render())
         subprocess.check_call([LLVM + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c",
@@ -148,9 +149,11 @@ def main():
     ap.add_argument("--vpl", type=int, default=0, help="disparities per lane of the full-size run (0: the library's rule)")
     ap.add_argument("--drop", default="", help="fl,fa: time ONLY the variant with these fractions of LOAD / ADD ops dropped "
                                                "(counter passes under rocprofv3: every launch of the run is that variant)")
+    ap.add_argument("--early", action="store_true", help="experimental: the program's first op dispatched from a scalar load")
     args = ap.parse_args()
-    global K_DEFAULT, RING, MINVGPR, PERSIST, PIPE, NTLOAD
+    global K_DEFAULT, RING, MINVGPR, PERSIST, PIPE, NTLOAD, EARLY
     K_DEFAULT, RING, MINVGPR, PERSIST, PIPE, NTLOAD = args.k, args.ring, args.minvgpr, args.persist, args.pipe, args.ntload
+    EARLY = args.early
     hip.require_device()
     allok = True
     for vpl in (() if args.skip_small else (4,) if RING else (4, 2, 3)):   # (no 8-byte buffer_load ... lds on gfx950)
