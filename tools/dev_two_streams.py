@@ -25,6 +25,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="cfg2"); ap.add_argument("--iters", type=int, default=16)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--pipe", type=int, default=0, help="the program-managed ring window (widest unit); programs from the Python builder")
+    ap.add_argument("--w", type=int, default=20); ap.add_argument("--minvgpr", type=int, default=0)
     args = ap.parse_args()
     hip.require_device()
     H, W, D = CONFIGS[args.config]
@@ -33,8 +35,8 @@ def main():
     outdir = os.path.join(ROOT, "mc-cnn-python_amd", "build", "asm")
     mods = {}
     for skip in (False, True):
-        g = gen.Gen(gen.Params(vpl=vpl, K=4, W=20, skip=skip)).build()
-        base = os.path.join(outdir, "two_streams_v%d_%d" % (vpl, int(skip)))
+        g = gen.Gen(gen.Params(vpl=vpl, K=4, W=args.w, skip=skip, pipe=args.pipe, minvgpr=args.minvgpr)).build()
+        base = os.path.join(outdir, "two_streams_v%d_%d_%d_%d_%d" % (vpl, int(skip), args.w, args.pipe, args.minvgpr))
         open(base + ".s", "w").write(g.render())
         import subprocess
         subprocess.check_call([dpc.LLVM + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c",
@@ -58,6 +60,15 @@ def main():
     want_l, want_r = want[0][0].clone(), want[1][0].clone()
     pf = [progs[0][:set_dwords], progs[1][:set_dwords]]
     ps = [progs[0][set_dwords:], progs[1][set_dwords:]]
+    if args.pipe or args.w != 20:      # another program format: the plain-Python builder
+        Lp = dict(L, pix=4 * Dp)
+        pf, ps = [], []
+        for sup in (sl, sr):
+            sup0 = sup.cpu().numpy().view(np.uint32).reshape(-1)[:H * W].reshape(H, W)
+            for lst, sk in ((pf, False), (ps, True)):
+                arr, m2 = ref.build_all(sup0, H, W, Lp, skip_unit=sk)
+                lst.append(torch.from_numpy(arr.view(np.int32)).cuda())
+        meta["stride"] = m2["stride"]
     grid2 = (8 * meta["band_groups"], meta["ngroups"], nchunks * 2)
     grid1 = (8 * meta["band_groups"], meta["ngroups"], nchunks)
 
