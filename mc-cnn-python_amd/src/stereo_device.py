@@ -1040,6 +1040,10 @@ class StereoMatcher(object):
         g = self._graphs.get(key)
         if g is None:
             self.workspace(*key)                 # may reset self._graphs: one shape resident at a time
+            # fresh side / right-chain streams for this capture: a stream never takes part in the captures of two graphs
+            # (see _right_stream)
+            self._side = None
+            self._right = None
             sl, sr = torch.empty_like(L, dtype=torch.float32), torch.empty_like(R, dtype=torch.float32)
             sl.copy_(L)
             sr.copy_(R)
