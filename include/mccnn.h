@@ -210,6 +210,11 @@ int mccnn_cbca_iter_prog_pair_wta(const float *in_left, float *out_left, const m
  * into the first iteration's input buffer - full again (stereo_device.cbca_prog_pair states the rule for any count). */
 int mccnn_cbca_prog_build_skip_pair(const mccnn_support_t *support_left, const mccnn_support_t *support_right, int D,
                                     int H, int W, int L, void *prog_left, void *prog_right, mccnn_stream_t stream);
+/* Both program sets from ONE pass over the support words (round 5): what mccnn_cbca_prog_build_pair followed by
+ * mccnn_cbca_prog_build_skip_pair write, word for word, in one launch and about half their time (the sweep steps of the
+ * two programs of a patch share a wave's lanes). */
+int mccnn_cbca_prog_build_both_pair(const mccnn_support_t *support_left, const mccnn_support_t *support_right, int D,
+                                    int H, int W, int L, void *prog_left, void *prog_right, mccnn_stream_t stream);
 int mccnn_cbca_iter_prog_pair_skip(const float *in_left, float *out_left, const mccnn_support_t *support_left,
                                    const void *prog_left, const float *in_right, float *out_right,
                                    const mccnn_support_t *support_right, const void *prog_right, int D, int H, int W,

@@ -105,22 +105,23 @@ struct StageEmitter {
     }
 };
 
-// One wave per patch (column group, row group, image); lane t builds sweep step t (a patch has at most
+// One wave per patch (column group, row group, image); a lane builds one sweep step (a patch has at most
 // 2 K + 2 R - 1 = 33) into an LDS staging column, a wave scan turns the lanes' op counts into positions, and the ops
 // go out (raw op i lives at dword i + i / 63, a REFILL closes every 64-op chunk).  (One thread per patch took
 // 0.91 ms per 750x500 pair: 600 waves of serial, divergent code.)
+// mode 0: the full programs; 1: the second set (set_dwords further on: the programs without the anchors whose support
+// region is the pixel itself, cbca_prog_build.h unit_region); 2 (round 5): BOTH sets from one pass over the support
+// words - the sweep steps of the full program on lanes 0 .., those of the skip program on the lanes behind them (the two
+// fit the 64 lanes unless both sweeps are longer than 32 steps: then one after the other), one scan, two outputs.
 __global__ __launch_bounds__(64) void cbca_prog_build_kernel(const Layout Larg, const uint32_t *__restrict__ sup0,
                                                              const uint32_t *__restrict__ sup1, uint32_t *__restrict__ prog0,
                                                              uint32_t *__restrict__ prog1, int H, int W, int ngroups,
-                                                             int stride, size_t set_dwords, int skip_set)
+                                                             int stride, size_t set_dwords, int mode)
 {
     // the handler offsets are looked up with per-lane indices: from LDS (a copy of the kernel argument), not from the
     // kernarg segment in memory (a dependent ~0.4 us load per op)
     __shared__ Layout L;
-    // blockIdx.z = image; skip_set 0 = the full programs, 1 = the second set (set_dwords further on): the programs
-    // without the anchors whose support region is the pixel itself (cbca_prog_build.h, unit_region)
-    const int lane = threadIdx.x, cg = blockIdx.x, rg = blockIdx.y, job = blockIdx.z;
-    const bool skip_unit = skip_set != 0;
+    const int lane = threadIdx.x, cg = blockIdx.x, rg = blockIdx.y, job = blockIdx.z;   // blockIdx.z = image
     {
         const int *src = reinterpret_cast<const int *>(&Larg);
         int *dst = reinterpret_cast<int *>(&L);
@@ -130,68 +131,97 @@ __global__ __launch_bounds__(64) void cbca_prog_build_kernel(const Layout Larg, 
     const int y0 = rg * L.K;
     if (y0 >= H) return;
     const uint32_t *sup = job ? sup1 : sup0;
-    uint32_t *out = (job ? prog1 : prog0) + (skip_unit ? set_dwords : 0) + ((size_t)rg * ngroups + cg) * stride;
+    uint32_t *const base = (job ? prog1 : prog0) + ((size_t)rg * ngroups + cg) * stride;
     // the patch's anchors (the same for every lane) and the lanes' work arrays live in LDS, not in scratch memory
-    __shared__ Patch P;
+    __shared__ Patch P2[2];                    // [0] every anchor, [1] without the unit-region anchors
     __shared__ uint8_t tmp[5 * MAXG][64];
+    int nsteps[2];
     {   // patch_setup (cbca_prog_build.h) with one anchor per lane: 20 independent loads instead of 20 in a row
         const int K = L.K, G = L.G, x0 = cg * L.G;
         const int k = lane / G, j = lane - k * G;
-        int lowest = y0, highest = y0, up = 0, dn = 0;
-        bool ok = false;
+        int up = 0, dn = 0;
+        bool ok[2] = {false, false};
+        int lowest[2] = {y0, y0}, highest[2] = {y0, y0};
         if (lane < K * G) {
             const int y = y0 + k, x = x0 + j;
-            ok = x < W && y < H;
-            if (ok) {
+            if (x < W && y < H) {
                 const uint32_t a = sup[(size_t)y * W + x];
-                if (skip_unit && unit_region(a)) {
-                    ok = false;
-                } else {
-                    const int u = (int)(a & 31u), d = (int)((a >> 5) & 31u);
-                    up = u < y ? u : y;
-                    dn = d < H - 1 - y ? d : H - 1 - y;
-                    lowest = y - up;
-                    highest = dn > 0 ? y + dn : y0;
-                }
+                ok[0] = true;
+                ok[1] = !unit_region(a);
+                const int u = (int)(a & 31u), d = (int)((a >> 5) & 31u);
+                up = u < y ? u : y;
+                dn = d < H - 1 - y ? d : H - 1 - y;
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    if (ok[s]) {
+                        lowest[s] = y - up;
+                        highest[s] = dn > 0 ? y + dn : y0;
+                    }
             }
         }
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            lowest = min(lowest, __shfl_xor(lowest, d));
-            highest = max(highest, __shfl_xor(highest, d));
-        }
-        const int nd = y0 + K - 1 - lowest + 1;
-        if (lane < K * G) P.sched[k][j] = sched_of(ok, K, k, up, dn, nd);
-        if (lane == 0) {
-            P.y0 = y0;
-            P.x0 = x0;
-            P.nd = nd;
-            P.na = highest - y0;
-            P.row0 = y0 - R > 0 ? y0 - R : 0;
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                lowest[s] = min(lowest[s], __shfl_xor(lowest[s], d));
+                highest[s] = max(highest[s], __shfl_xor(highest[s], d));
+            }
+            const int nd = y0 + K - 1 - lowest[s] + 1, na = highest[s] - y0;
+            if (lane < K * G) P2[s].sched[k][j] = sched_of(ok[s], K, k, ok[s] ? up : 0, ok[s] ? dn : 0, nd);
+            if (lane == 0) {
+                P2[s].y0 = y0;
+                P2[s].x0 = x0;
+                P2[s].nd = nd;
+                P2[s].na = na;
+                P2[s].row0 = y0 - R > 0 ? y0 - R : 0;
+            }
+            nsteps[s] = nd + na;
         }
     }
     __syncthreads();
     const RowTmpT<uint8_t> T = {{&tmp[0 * MAXG][lane], 64}, {&tmp[1 * MAXG][lane], 64}, {&tmp[2 * MAXG][lane], 64},
                                 {&tmp[3 * MAXG][lane], 64}, {&tmp[4 * MAXG][lane], 64}};
-    const int nsteps = P.nd + P.na;
     // one pass: a lane's ops go to an LDS staging column first (their position in the program is known only once every
     // lane has counted its own), then a wave scan places them
     __shared__ uint32_t stage[kStageOps][64];
-    StageEmitter c = {&stage[0][lane], 0};
-    if (lane < nsteps) emit_row(L, P, sup, W, lane, T, c);
-    int incl = c.n;                                                   // inclusive scan over the lanes
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-    }
-    const int total = __shfl(incl, 63);
     const uint32_t refill = (uint32_t)L.refill | ((uint32_t)L.M0 << 16);
-    WriteEmitter w = {out, incl - c.n, stride, refill};
-    for (int i = 0; i < c.n; ++i) w.op(stage[i][lane]);
-    if (lane == 0) {
-        WriteEmitter e = {out, total, stride, refill};
-        e.op((uint32_t)L.end | ((uint32_t)L.M0 << 16));
+    const uint32_t endop = (uint32_t)L.end | ((uint32_t)L.M0 << 16);
+    // lanes [0, nA) build set sA, lanes [nA, nA + nB) set sB (nB = 0: one set only)
+    auto pass = [&](int sA, int nA, int sB, int nB) {
+        StageEmitter c = {&stage[0][lane], 0};
+        const bool inB = lane >= nA;
+        const int sel = inB ? sB : sA, t = inB ? lane - nA : lane;
+        if (lane < nA + nB) emit_row(L, P2[sel], sup, W, t, T, c);
+        int incl = c.n;                                               // inclusive scan over the lanes
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        const int total = __shfl(incl, 63);
+        const int totalA = nA > 0 ? __shfl(incl, nA - 1) : 0;
+        uint32_t *out = base + (sel ? set_dwords : 0);
+        WriteEmitter w = {out, incl - c.n - (inB ? totalA : 0), stride, refill};
+        for (int i = 0; i < c.n; ++i) w.op(stage[i][lane]);
+        if (lane == 0) {
+            WriteEmitter e = {base + (sA ? set_dwords : 0), totalA, stride, refill};
+            e.op(endop);
+        }
+        if (lane == 1 && sB != sA) {
+            WriteEmitter e = {base + (sB ? set_dwords : 0), total - totalA, stride, refill};
+            e.op(endop);
+        }
+    };
+    if (mode == 0) {
+        pass(0, nsteps[0], 0, 0);
+    } else if (mode == 1) {
+        pass(1, nsteps[1], 1, 0);
+    } else if (nsteps[0] + nsteps[1] <= 64) {
+        pass(0, nsteps[0], 1, nsteps[1]);
+    } else {
+        pass(0, nsteps[0], 0, 0);
+        __syncthreads();
+        pass(1, nsteps[1], 1, 0);
     }
 }
 
@@ -269,7 +299,8 @@ extern "C" size_t mccnn_cbca_prog_bytes(int D, int H, int W)
     return 2 * prog::set_bytes(s);      // the full programs, then the skip programs
 }
 
-static int prog_build(const char *who, int set, const mccnn_support_t *support_left, const mccnn_support_t *support_right,
+// mode 0: the full programs, 1: the skip programs, 2: both sets in one launch
+static int prog_build(const char *who, int mode, const mccnn_support_t *support_left, const mccnn_support_t *support_right,
                       int D, int H, int W, int L, void *prog_left, void *prog_right, mccnn_stream_t stream)
 {
     using namespace mccnn;
@@ -287,9 +318,10 @@ static int prog_build(const char *who, int set, const mccnn_support_t *support_l
     hipLaunchKernelGGL(prog::cbca_prog_build_kernel, grid, dim3(64), 0, (hipStream_t)stream, prog::kLayouts[s.vpl - 2],
                        reinterpret_cast<const uint32_t *>(support_left), reinterpret_cast<const uint32_t *>(support_right),
                        reinterpret_cast<uint32_t *>(prog_left), reinterpret_cast<uint32_t *>(prog_right), H, W, s.ngroups,
-                       s.stride, prog::set_bytes(s) / 4, set);
+                       s.stride, prog::set_bytes(s) / 4, mode);
     rc = check_launch(who);
-    if (rc == 0) {
+    for (int set = 0; rc == 0 && set < 2; ++set) {
+        if (mode != 2 && mode != set) continue;
         const unsigned long long gl = support_generation(support_left), gr = support_generation(support_right);
         std::lock_guard<std::mutex> lock(prog::g_built_mu);
         auto &reg = prog::g_built[set];
@@ -310,6 +342,14 @@ extern "C" int mccnn_cbca_prog_build_pair(const mccnn_support_t *support_left, c
                                           mccnn_stream_t stream)
 {
     return prog_build("mccnn_cbca_prog_build_pair", 0, support_left, support_right, D, H, W, L, prog_left, prog_right, stream);
+}
+
+extern "C" int mccnn_cbca_prog_build_both_pair(const mccnn_support_t *support_left, const mccnn_support_t *support_right,
+                                               int D, int H, int W, int L, void *prog_left, void *prog_right,
+                                               mccnn_stream_t stream)
+{
+    return prog_build("mccnn_cbca_prog_build_both_pair", 2, support_left, support_right, D, H, W, L, prog_left, prog_right,
+                      stream);
 }
 
 extern "C" int mccnn_cbca_prog_build_skip_pair(const mccnn_support_t *support_left, const mccnn_support_t *support_right,

@@ -48,6 +48,7 @@ SIGNATURES = {
     "mccnn_cbca_prog_build_pair": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mccnn_cbca_iter_prog_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mccnn_cbca_prog_build_skip_pair": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mccnn_cbca_prog_build_both_pair": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mccnn_cbca_iter_prog_pair_skip": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mccnn_cbca_iter_prog": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mccnn_cbca_iter_prog_skip": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

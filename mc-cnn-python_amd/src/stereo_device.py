@@ -361,15 +361,21 @@ def cbca_prog_build_pair(support_l, support_r, D, distance_threshold, progs, whi
     """Compiles both images' support regions into the per-patch programs of the assembly aggregation kernel: once per
     pair, after cross_arms_pair, for all iterations.  which: "full" (mccnn_cbca_prog_build_pair: what every iteration can
     run), "skip" (mccnn_cbca_prog_build_skip_pair: the second set in the same buffers, which second and later iterations
-    run, cbca_prog_pair) or "both" - two launches, so a caller may put the second one beside the first iterations."""
+    run, cbca_prog_pair), "both" (mccnn_cbca_prog_build_both_pair: the two sets from one pass over the support words, one
+    launch of about the time of either of the others) or "both_two_launches" (the first two one after the other)."""
     H, W = support_l.shape
     _check_support(support_l, H, W, "cbca_prog_build_pair")
     _check_support(support_r, H, W, "cbca_prog_build_pair")
-    if which not in ("full", "skip", "both"):
-        raise ValueError("cbca_prog_build_pair: which must be 'full', 'skip' or 'both'")
+    if which not in ("full", "skip", "both", "both_two_launches"):
+        raise ValueError("cbca_prog_build_pair: which must be 'full', 'skip', 'both' or 'both_two_launches'")
     lib = hip.load()
+    if which == "both":       # one launch, one pass over the support words for the two sets
+        hip.check(lib.mccnn_cbca_prog_build_both_pair(hip.ptr(support_l), hip.ptr(support_r), int(D), H, W,
+                                                      int(distance_threshold), hip.ptr(progs[0]), hip.ptr(progs[1]),
+                                                      hip.stream()), "mccnn_cbca_prog_build_both_pair")
+        return progs
     for name, fn in (("full", lib.mccnn_cbca_prog_build_pair), ("skip", lib.mccnn_cbca_prog_build_skip_pair)):
-        if which in (name, "both"):
+        if which in (name, "both_two_launches"):
             hip.check(fn(hip.ptr(support_l), hip.ptr(support_r), int(D), H, W, int(distance_threshold), hip.ptr(progs[0]),
                          hip.ptr(progs[1]), hip.stream()), "mccnn_cbca_prog_build_%spair" % ("skip_" if name == "skip" else ""))
     return progs
@@ -719,7 +725,7 @@ class StereoMatcher(object):
 
     def __init__(self, net, hp=None, cv_mode=hip.MCCNN_CV_EXACT, cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER,
                  feature_tile_rows=None, extras=None, features="auto", layout="auto", cbca_kernel="auto",
-                 on_saturation="fallback", skip_unit_regions=True, two_chains=True):
+                 on_saturation="fallback", skip_unit_regions=True, two_chains=True, one_launch_builder=True):
         self.device = hip.require_device()
         self.net = net
         self.hp = dict(DEFAULT_HP)
@@ -759,6 +765,9 @@ class StereoMatcher(object):
         # the program-driven aggregation as two chains of one-volume launches on two streams (cbca_prog_pair,
         # right_stream): same bits; False = one two-volume launch per iteration
         self.two_chains = bool(two_chains)
+        # both program sets from one launch beside the cost volume (mccnn_cbca_prog_build_both_pair); False = round 4's
+        # two launches, the skip programs beside the first aggregation (A/B measurements)
+        self.one_launch_builder = bool(one_launch_builder)
         # opt-in departures from the reference (they change the output): the paper's rules it leaves out, and the
         # scalar promotion of the NumPy it was written for
         self.extras = dict(both_view_support=False, interpolation_directions=4, occlusion_from_left=False,
@@ -864,15 +873,17 @@ class StereoMatcher(object):
         sides = [hip.MCCNN_SIDE_LEFT, hip.MCCNN_SIDE_RIGHT]
 
         # The support arms and the aggregation programs depend on the images only: without per-stage timing they run
-        # on a side stream - arms + full programs beside the cost volume, the skip programs (first needed by the second
-        # iteration of the second aggregation) beside the first aggregation and SGM.  Measured at cfg2 (one box, 100
-        # pairs each, twice): everything on the main stream 9.22 / 9.22 ms, everything beside the conv stack 9.19 /
-        # 9.12 (the builder's waves slow the matrix-core kernels down by what they save), this placement 9.14 / 9.06.
+        # on a side stream beside the cost volume - the arms and, since round 5, both program sets in one launch (round
+        # 4 built the skip programs in a launch of their own beside the first aggregation and SGM).  Round-4
+        # measurements at cfg2 (one box, 100 pairs each, twice): everything on the main stream 9.22 / 9.22 ms,
+        # everything beside the conv stack 9.19 / 9.12 (the builder's waves slow the matrix-core kernels down by what
+        # they save), beside the cost volume 9.14 / 9.06.
         overlap = timer is _NO_TIMER
         skip_ready = full_ready = sup_l = sup_r = None
 
         def side_work(stage):
-            """stage 0: support arms + the full programs; stage 1: the skip programs."""
+            """stage 0: support arms + both program sets (or, one_launch_builder=False, the full programs; stage 1: the
+            skip programs)."""
             nonlocal skip_ready, full_ready, sup_l, sup_r
             if self._side is None:
                 self._side = torch.cuda.Stream()
@@ -881,10 +892,13 @@ class StereoMatcher(object):
                 if stage == 0:
                     sup_l, sup_r = cross_arms_pair(L, R, hp["cbca_intensity"], hp["cbca_distance"], ws["sup_l"], ws["sup_r"])
                     if ws["progs"] is not None:
-                        cbca_prog_build_pair(sup_l, sup_r, D, hp["cbca_distance"], ws["progs"], "full")
+                        # both program sets from one pass over the support words (round 5: one launch of about the
+                        # time either of the two earlier launches took)
+                        cbca_prog_build_pair(sup_l, sup_r, D, hp["cbca_distance"], ws["progs"],
+                                             "both" if (self.skip_unit_regions and self.one_launch_builder) else "full")
                     full_ready = torch.cuda.Event()
                     full_ready.record(self._side)
-                elif ws["progs"] is not None and self.skip_unit_regions:
+                elif ws["progs"] is not None and self.skip_unit_regions and not self.one_launch_builder:
                     cbca_prog_build_pair(sup_l, sup_r, D, hp["cbca_distance"], ws["progs"], "skip")
                     skip_ready = torch.cuda.Event()
                     skip_ready.record(self._side)
@@ -912,7 +926,7 @@ class StereoMatcher(object):
 
         if overlap:
             torch.cuda.current_stream().wait_event(full_ready)
-            if ws["progs"] is not None:
+            if ws["progs"] is not None and not self.one_launch_builder:
                 side_work(1)
         else:
             timer.start("cross_arms")
