@@ -376,8 +376,15 @@ def main():
     # second seeded scene class - the flat blobs without the texture half (synthetic.make_pair(texture=False)): a few
     # per cent of unit-region pixels, support regions of several hundred pixels almost everywhere, i.e. the reference's
     # running sums (pf:157-161) at their longest: the aggregation is then bound by its additions, not by bytes.
-    noskip_ms = worst_ms = worst_unit = None
+    noskip_ms = worst_ms = worst_unit = free_ms = None
     if not args.no_bounds and matcher.pixel_major() and matcher.workspace(H, W, D)["progs"] is not None:
+        # an opt-in launch structure (StereoMatcher(free_chains=True)): each volume's aggregation -> SGM -> aggregation
+        # as one free-running chain of one-volume launches, same bits
+        m4 = sd.StereoMatcher(net, cv_mode=matcher.cv_mode, cbca_order=matcher.cbca_order, features=matcher.features,
+                              on_saturation="ignore", free_chains=True)
+        m4._ws = matcher._ws
+        free_ms = timed(m4, 10)
+        del m4
         m2 = sd.StereoMatcher(net, cv_mode=matcher.cv_mode, cbca_order=matcher.cbca_order, features=matcher.features,
                               on_saturation="ignore", skip_unit_regions=False)
         m2._ws = matcher._ws
@@ -587,6 +594,7 @@ def main():
         # how much of the headline is a property of this image (10 / 3 graph replays each, same box, outside `value`)
         "unit_region_pixels": unit_fraction,
         "ms_per_step_without_skipping": round(noskip_ms, 3) if noskip_ms is not None else None,
+        "ms_per_step_free_running_chains": round(free_ms, 3) if free_ms is not None else None,
         "worst_case_ms_per_step": round(worst_ms, 3) if worst_ms is not None else None,
         "worst_case_scene": {"what": "synthetic.make_pair(texture=False): the flat blobs alone, support regions of several "
                                      "hundred pixels almost everywhere - the aggregation is bound by the reference's "

@@ -488,6 +488,29 @@ def cbca_prog_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, progs, D, i
     return (sl, dl), (sr, dr)
 
 
+def cbca_prog_chain(vol, tmp, support, prog, D, iterations, distance_threshold, first=0, total=None, fused_last=False,
+                    skip_unit_regions=True, skip_ready=None):
+    """Iterations first .. iterations-1 of ONE volume's aggregation on the current stream (mccnn_cbca_iter_prog /
+    _skip; cbca_prog_pair's rule for which iterations leave the unit-region pixels alone, with `total` = the length of
+    the whole aggregation and fused_last = its last iteration carries the WTA and is not part of the chain)."""
+    H, W, Dp = vol.shape
+    lib = hip.load()
+    n = int(total if total is not None else iterations)
+    src, dst = vol, tmp
+    waited = False
+    for it in range(int(first), int(iterations)):
+        skip = bool(skip_unit_regions) and it >= 1 and not (fused_last and it == n - 1) and not (n % 2 == 0 and it == n - 1)
+        if skip and skip_ready is not None and not waited:
+            torch.cuda.current_stream().wait_event(skip_ready)
+            waited = True
+        fn, who = ((lib.mccnn_cbca_iter_prog_skip, "mccnn_cbca_iter_prog_skip") if skip
+                   else (lib.mccnn_cbca_iter_prog, "mccnn_cbca_iter_prog"))
+        hip.check(fn(hip.ptr(src), hip.ptr(dst), hip.ptr(support), hip.ptr(prog), int(D), H, W, int(distance_threshold),
+                     hip.stream()), who)
+        src, dst = dst, src
+    return src, dst
+
+
 def cbca_both_views(vol, tmp, support_self, support_other, iterations, distance_threshold, side, timer=None):
     """`iterations` rounds of cross-based averaging with the paper's two-view support regions (opt-in extra, see
     mccnn_cbca_iter_both): arms intersected with the other view's at the partner pixel x -/+ d.  Same ping-pong
@@ -725,7 +748,8 @@ class StereoMatcher(object):
 
     def __init__(self, net, hp=None, cv_mode=hip.MCCNN_CV_EXACT, cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER,
                  feature_tile_rows=None, extras=None, features="auto", layout="auto", cbca_kernel="auto",
-                 on_saturation="fallback", skip_unit_regions=True, two_chains=True, one_launch_builder=True):
+                 on_saturation="fallback", skip_unit_regions=True, two_chains=True, one_launch_builder=True,
+                 side_early=False, free_chains=False):
         self.device = hip.require_device()
         self.net = net
         self.hp = dict(DEFAULT_HP)
@@ -768,6 +792,13 @@ class StereoMatcher(object):
         # both program sets from one launch beside the cost volume (mccnn_cbca_prog_build_both_pair); False = round 4's
         # two launches, the skip programs beside the first aggregation (A/B measurements)
         self.one_launch_builder = bool(one_launch_builder)
+        # options measured with tools/dev_ab_matchers.py (profiles/r05_ab_matcher_options.txt): side_early - the side
+        # stream's work beside the conv stack instead of beside the cost volume (+0.04 ms: worse); free_chains - each
+        # volume's aggregation -> SGM -> aggregation as ONE free-running chain of one-volume launches, no join between
+        # the stages (-0.10 ms, same bits; opt-in because the SGM passes then run as one-volume launches beside whatever
+        # the other chain is doing, which no per-kernel figure describes)
+        self.side_early = bool(side_early)
+        self.free_chains = bool(free_chains)
         # opt-in departures from the reference (they change the output): the paper's rules it leaves out, and the
         # scalar promotion of the NumPy it was written for
         self.extras = dict(both_view_support=False, interpolation_directions=4, occlusion_from_left=False,
@@ -903,13 +934,15 @@ class StereoMatcher(object):
                     skip_ready = torch.cuda.Event()
                     skip_ready.record(self._side)
 
+        if overlap and self.side_early:
+            side_work(0)
         timer.start("features")
         if self.features == "split_f16":
             fl, fr = self.net.features_pair_hwc_split(L, R)
         else:
             fl, fr = self.net.features_pair_hwc(L, R, tile_rows=self.feature_tile_rows)
         timer.stop()
-        if overlap:
+        if overlap and not self.side_early:
             side_work(0)
 
         # the bit-exact variant writes its cost volume pixel-major right away (nothing converts layouts after that)
@@ -956,21 +989,52 @@ class StereoMatcher(object):
                                       skip_unit_regions=self.skip_unit_regions,
                                       right_stream=self._right_stream() if self.two_chains else None, **kw)
 
+            free = (self.free_chains and overlap and keep is None and progs is not None and self.two_chains)
+            if free:
+                n1, n2 = int(hp["cbca_num_iterations1"]), int(hp["cbca_num_iterations2"])
+                fuse = n2 >= 1 and D <= cbca_hwd_wta_max_d()
+                if "scratch2" not in ws:
+                    ws["scratch2"] = sgm_scratch(H, W, D, self.device)
+                main_s, right_s = torch.cuda.current_stream(), self._right_stream()
+                right_s.wait_stream(main_s)
+                ends = []
+                for st, v, t, sup, prog, side, scr in ((main_s, lh, as_hwd(b0), sup_l, progs[0], sides[0], ws["scratch"]),
+                                                       (right_s, rh, as_hwd(b1), sup_r, progs[1], sides[1], ws["scratch2"])):
+                    with torch.cuda.stream(st):
+                        v, t = cbca_prog_chain(v, t, sup, prog, D, n1, hp["cbca_distance"],
+                                               skip_unit_regions=self.skip_unit_regions, skip_ready=skip_ready)
+                        sgm_average_hwd(L, R, [v], [side], D, hp["sgm_P1"], hp["sgm_P2"], hp["sgm_Q1"], hp["sgm_Q2"],
+                                        hp["sgm_D"], hp["sgm_V"], scr, timer)
+                        v, t = cbca_prog_chain(v, t, sup, prog, D, n2 - 1 if fuse else n2, hp["cbca_distance"], total=n2,
+                                               fused_last=fuse, skip_unit_regions=self.skip_unit_regions,
+                                               skip_ready=skip_ready)
+                        ends.append((v, t))
+                main_s.wait_stream(right_s)
+                (lh, lt), (rh, rt) = ends
+                if fuse:
+                    hip.check(hip.load().mccnn_cbca_iter_prog_pair_wta(
+                        hip.ptr(lh), hip.ptr(lt), hip.ptr(sup_l), hip.ptr(progs[0]), hip.ptr(rh), hip.ptr(rt), hip.ptr(sup_r),
+                        hip.ptr(progs[1]), int(D), H, W, int(hp["cbca_distance"]), hip.ptr(m[0]), hip.ptr(m[1]), 0,
+                        hip.stream()), "mccnn_cbca_iter_prog_pair_wta")
+                    lh, lt, rh, rt = lt, lh, rt, rh
             timer.span_start("aggregation_1")
-            (lh, lt), (rh, rt) = aggregate_hwd(lh, as_hwd(b0), rh, as_hwd(b1), hp["cbca_num_iterations1"])
+            if not free:
+                (lh, lt), (rh, rt) = aggregate_hwd(lh, as_hwd(b0), rh, as_hwd(b1), hp["cbca_num_iterations1"])
             timer.span_stop("aggregation_1")
             if keep is not None:
                 keep["cbca1"] = (hwd_to_dhw(lh, D), hwd_to_dhw(rh, D))
-            sgm_average_hwd(L, R, [lh, rh], sides, D, hp["sgm_P1"], hp["sgm_P2"], hp["sgm_Q1"], hp["sgm_Q2"],
-                            hp["sgm_D"], hp["sgm_V"], ws["scratch"], timer)
+            if not free:
+                sgm_average_hwd(L, R, [lh, rh], sides, D, hp["sgm_P1"], hp["sgm_P2"], hp["sgm_Q1"], hp["sgm_Q2"],
+                                hp["sgm_D"], hp["sgm_V"], ws["scratch"], timer)
             if keep is not None:
                 keep["sgm"] = (hwd_to_dhw(lh, D), hwd_to_dhw(rh, D))
             # the last iteration carries the WTA of both results (and leaves the right volume, which nothing else
             # reads, unwritten) when a wave holds all disparities of a pixel
             fuse = int(hp["cbca_num_iterations2"]) >= 1 and D <= cbca_hwd_wta_max_d()
             timer.span_start("aggregation_2")
-            (lh, lt), (rh, rt) = aggregate_hwd(lh, lt, rh, rt, hp["cbca_num_iterations2"],
-                                               wta_out=(m[0], m[1]) if fuse else None, store_right=keep is not None)
+            if not free:
+                (lh, lt), (rh, rt) = aggregate_hwd(lh, lt, rh, rt, hp["cbca_num_iterations2"],
+                                                   wta_out=(m[0], m[1]) if fuse else None, store_right=keep is not None)
             timer.span_stop("aggregation_2")
             if overlap and skip_ready is not None:
                 torch.cuda.current_stream().wait_event(skip_ready)      # joins the side stream whatever the iteration count
