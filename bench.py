@@ -376,14 +376,16 @@ def main():
     # second seeded scene class - the flat blobs without the texture half (synthetic.make_pair(texture=False)): a few
     # per cent of unit-region pixels, support regions of several hundred pixels almost everywhere, i.e. the reference's
     # running sums (pf:157-161) at their longest: the aggregation is then bound by its additions, not by bytes.
-    noskip_ms = worst_ms = worst_unit = free_ms = None
+    noskip_ms = worst_ms = worst_unit = joined_ms = natural_ms = natural_unit = None
+    in_flight = {}
+    voxels_hint = H * W * D
     if not args.no_bounds and matcher.pixel_major() and matcher.workspace(H, W, D)["progs"] is not None:
-        # an opt-in launch structure (StereoMatcher(free_chains=True)): each volume's aggregation -> SGM -> aggregation
-        # as one free-running chain of one-volume launches, same bits
+        # round 5's launch structure (StereoMatcher(free_chains=False)): the two chains of one-volume aggregation launches
+        # join after every stage and the SGM passes are two-volume launches; same bits
         m4 = sd.StereoMatcher(net, cv_mode=matcher.cv_mode, cbca_order=matcher.cbca_order, features=matcher.features,
-                              on_saturation="ignore", free_chains=True)
+                              on_saturation="ignore", free_chains=False)
         m4._ws = matcher._ws
-        free_ms = timed(m4, 10)
+        joined_ms = timed(m4, 10)
         del m4
         m2 = sd.StereoMatcher(net, cv_mode=matcher.cv_mode, cbca_order=matcher.cbca_order, features=matcher.features,
                               on_saturation="ignore", skip_unit_regions=False)
@@ -399,9 +401,47 @@ def main():
         wsw = m3.workspace(H, W, D)
         worst_unit = {k2: round(float(((wsw[k] & 0xfffff) == 0).float().mean().item()), 4)
                       for k, k2 in (("sup_l", "left"), ("sup_r", "right"))}
+        # (c) the third seeded scene class - synthetic.make_pair(kind="natural"): a 1/f amplitude spectrum, 8 bit,
+        # standardised like match.py:120-121 - i.e. the second-order statistics of a photograph: the arm threshold is
+        # about one grey level, almost every support region is the pixel itself and the skip launches are almost empty
+        Ln, Rn, _, _, _ = synthetic.make_pair(H, W, D, seed=100 + rank, kind="natural")
+        dln, drn = torch.from_numpy(Ln[:, :, 0]).cuda(), torch.from_numpy(Rn[:, :, 0]).cuda()
+        natural_ms = timed(m3, 10, dln, drn)
+        natural_unit = {k2: round(float(((wsw[k] & 0xfffff) == 0).float().mean().item()), 4)
+                        for k, k2 in (("sup_l", "left"), ("sup_r", "right"))}
         del m3
         matcher.match(dl, dr, D)                 # the shared workspace holds the benchmark pair's arms again
         torch.cuda.synchronize()
+        # Throughput with several pairs in flight - the reference's own scheme is several match.py processes with
+        # different -s/-e windows on one GPU (match.py:26-28): N matchers, each with its own workspace, streams and
+        # captured graph, replayed round-robin on N streams.  Outside `value` (the headline stays one pair per GPU).
+        for n_fl in (2, 4):
+            free_b, _total_b = torch.cuda.mem_get_info()
+            need = n_fl * 6.5 * 4.0 * voxels_hint                      # ~4 volumes + programs + conv activations each
+            if need > 0.8 * free_b:
+                continue
+            ms_ = [sd.StereoMatcher(net, cv_mode=matcher.cv_mode, cbca_order=matcher.cbca_order, features=matcher.features,
+                                    on_saturation="ignore") for _ in range(n_fl)]
+            sts = [torch.cuda.Stream() for _ in range(n_fl)]
+            try:
+                for m_, st_ in zip(ms_, sts):
+                    with torch.cuda.stream(st_):
+                        m_.match_graph(dl, dr, D)
+                        m_.match_graph(dl, dr, D)
+                torch.cuda.synchronize()
+                npairs = 12 * n_fl
+                t4 = time.perf_counter()
+                for i in range(npairs):
+                    with torch.cuda.stream(sts[i % n_fl]):
+                        last_ = ms_[i % n_fl].match_graph(dl, dr, D)
+                torch.cuda.synchronize()
+                in_flight[n_fl] = {"ms_per_pair": round((time.perf_counter() - t4) / npairs * 1e3, 3),
+                                   "final_map_equals_the_timed_pair": bool(torch.equal(last_.view(torch.int32),
+                                                                                       out.view(torch.int32)))}
+            except Exception as e:                                     # e.g. capture refused beside another graph
+                in_flight[n_fl] = {"error": str(e)[:200]}
+            del ms_, sts
+            torch.cuda.empty_cache()
     hl, hr = torch.from_numpy(L[:, :, 0].copy()).pin_memory(), torch.from_numpy(R[:, :, 0].copy()).pin_memory()
     t2 = time.perf_counter()                     # match.py's own region: host images in, host map out
     for _ in range(nside):
@@ -413,7 +453,10 @@ def main():
     value = world * voxels * args.steps / elapsed_max / 1e6
     stages = {k: float(np.mean(v)) for k, v in timer.summary_ms().items()}          # mean ms per launch / stage
     counts = {k: len(v) // nside for k, v in timer.summary_ms().items()}
-    per_step = {k: stages[k] * counts[k] for k in stages}                            # ms per step
+    # One-volume launches run as two concurrent chains (left volume on the main stream, right volume on a second one):
+    # their per-launch durations overlap pairwise in wall time, so a step is charged half of their sum.
+    CONCURRENT = ("cbca_iter_prog", "cbca_iter_prog_skip", "sgm_pass_one_volume")
+    per_step = {k: stages[k] * counts[k] * (0.5 if k in CONCURRENT else 1.0) for k in stages}     # ms per step
     vol_bytes = 4.0 * voxels
     # algorithmic bytes per launch (SURVEY 8d / DESIGN.md): one read + one write of every voxel the launch owns
     algo = {
@@ -423,6 +466,7 @@ def main():
         "cbca_iter_prog_pair": 2 * 2 * vol_bytes,  # the same, program-driven assembly kernel (the default)
         "cbca_iter_prog": 2 * vol_bytes,           # ... one volume per launch (two chains of launches on two streams)
         "sgm_pass": 2 * 2 * vol_bytes,    # one direction on BOTH volumes (one launch advances left + right)
+        "sgm_pass_one_volume": 2 * vol_bytes,      # one direction on ONE volume (the free-running chains)
         "sgm_first_pass": 2 * 2 * vol_bytes,
     }
     # Iterations 2.. of an aggregation leave the pixels alone whose support region is the pixel itself (their value is
@@ -470,7 +514,7 @@ def main():
     # a launch's duration - by the events on its own stream, and in rocprofv3's table - is its duration WHILE ITS TWIN
     # RUNS, so the per-launch figure is that of a kernel with half of the chip; the aggregation as a stage is priced
     # from the bracket around the whole stage below (`aggregation_stages`).
-    for k in ("cbca_iter_prog", "cbca_iter_prog_skip"):
+    for k in CONCURRENT:
         if k in rooflines:
             r = rooflines[k]
             r["concurrent_launches"] = 2
@@ -544,9 +588,12 @@ def main():
     dominant = max((k for k in rooflines if rooflines[k]["bound"] == "hbm" and k in algo), key=lambda k: per_step[k]) \
         if any(k in algo for k in rooflines) else None
     # SGM as a stage (what north_star's >= 50 % target is quoted on): 4 passes + the two layout changes
-    sgm_stage_ms = (per_step.get("sgm_pass", 0.0) + per_step.get("sgm_first_pass", 0.0) +
-                    per_step.get("dhw_to_hwd", 0.0) + per_step.get("hwd_to_dhw", 0.0))
-    sgm_kern_ms = per_step.get("sgm_pass", 0.0) + per_step.get("sgm_first_pass", 0.0)
+    sgm_kern_ms = (per_step.get("sgm_pass", 0.0) + per_step.get("sgm_pass_one_volume", 0.0) +
+                   per_step.get("sgm_first_pass", 0.0))
+    sgm_stage_ms = sgm_kern_ms + per_step.get("dhw_to_hwd", 0.0) + per_step.get("hwd_to_dhw", 0.0)
+    sgm_span_ms = spans.get("sgm")     # the bracket around the four passes (free-running chains: one per chain, on its stream)
+    if sgm_span_ms is not None and matcher.pixel_major():
+        sgm_stage_ms = sgm_span_ms
     result = {
         "metric": "Mdisparities/s (HxWxD / s) end-to-end match.py timed region, images resident in HBM",
         "value": round(value, 2), "unit": "Mdisparities/s", "n_gpus": world, "steps": args.steps,
@@ -568,7 +615,10 @@ def main():
                    "hand-written matrix-core convolutions (float32 in/out; every operand as two f16 parts, 3 products per "
                    "multiply, float32 accumulation with the cross terms in their own accumulator: 2.6e-7 .. 3.1e-7 from a "
                    "float64 evaluation where the library path is 2.7e-7 .. 2.8e-7, profiles/parity_features_split_r04.json)",
-                   "launch": "one hipGraph replay per pair" if use_graph else "kernel by kernel",
+                   "launch": ("one hipGraph replay per pair" if use_graph else "kernel by kernel") +
+                   ("; each volume's aggregation -> SGM -> aggregation is one free-running chain of one-volume launches "
+                    "on its own stream (StereoMatcher's default since round 6), joined in front of the WTA-carrying "
+                    "last aggregation launch" if (matcher.free_chains and matcher.two_chains and matcher.pixel_major()) else ""),
                    "weights": "converted reference checkpoint" if os.path.isfile(wpath) else "random init"},
         "roofline": dict(rooflines[dominant], kernel=dominant) if dominant else None,
         "rooflines": rooflines,
@@ -576,6 +626,9 @@ def main():
         # concurrent one-volume launches achieve together
         "aggregation_stages": agg_stages,
         "sgm_stage": {"ms": round(sgm_stage_ms, 4), "algorithmic_bytes": int(4 * 2 * 2 * vol_bytes),
+                      "how": ("bracket around the four passes of a chain, recorded on the chain's own stream (mean of the left "
+                              "and the right chain, which run at the same time): both volumes' bytes over that span")
+                      if sgm_span_ms is not None and matcher.pixel_major() else "sum of the launches' events",
                       "achieved_GBs": round(4 * 2 * 2 * vol_bytes / (sgm_stage_ms * 1e-3) / 1e9, 1) if sgm_stage_ms else None,
                       "frac_of_hbm_peak": round(4 * 2 * 2 * vol_bytes / (sgm_stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                       if sgm_stage_ms else None},
@@ -594,7 +647,14 @@ def main():
         # how much of the headline is a property of this image (10 / 3 graph replays each, same box, outside `value`)
         "unit_region_pixels": unit_fraction,
         "ms_per_step_without_skipping": round(noskip_ms, 3) if noskip_ms is not None else None,
-        "ms_per_step_free_running_chains": round(free_ms, 3) if free_ms is not None else None,
+        "ms_per_step_chains_joined_after_every_stage": round(joined_ms, 3) if joined_ms is not None else None,
+        "natural_scene_ms_per_step": round(natural_ms, 3) if natural_ms is not None else None,
+        "natural_scene": {"what": "synthetic.make_pair(kind='natural'): 1/f amplitude spectrum, 8 bit, standardised like "
+                                  "match.py:120-121; the arm threshold is about one grey level, so almost every support "
+                                  "region is the pixel itself (10 graph replays)",
+                          "unit_region_pixels": natural_unit} if natural_ms is not None else None,
+        # N pairs in flight on N streams (N matchers with their own workspaces and graphs): throughput, not latency
+        "ms_per_pair_two_in_flight": in_flight.get(2), "ms_per_pair_four_in_flight": in_flight.get(4),
         "worst_case_ms_per_step": round(worst_ms, 3) if worst_ms is not None else None,
         "worst_case_scene": {"what": "synthetic.make_pair(texture=False): the flat blobs alone, support regions of several "
                                      "hundred pixels almost everywhere - the aggregation is bound by the reference's "

@@ -489,7 +489,7 @@ def cbca_prog_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, progs, D, i
 
 
 def cbca_prog_chain(vol, tmp, support, prog, D, iterations, distance_threshold, first=0, total=None, fused_last=False,
-                    skip_unit_regions=True, skip_ready=None):
+                    skip_unit_regions=True, skip_ready=None, timer=None):
     """Iterations first .. iterations-1 of ONE volume's aggregation on the current stream (mccnn_cbca_iter_prog /
     _skip; cbca_prog_pair's rule for which iterations leave the unit-region pixels alone, with `total` = the length of
     the whole aggregation and fused_last = its last iteration carries the WTA and is not part of the chain)."""
@@ -498,6 +498,7 @@ def cbca_prog_chain(vol, tmp, support, prog, D, iterations, distance_threshold, 
     n = int(total if total is not None else iterations)
     src, dst = vol, tmp
     waited = False
+    timer = timer or _NO_TIMER
     for it in range(int(first), int(iterations)):
         skip = bool(skip_unit_regions) and it >= 1 and not (fused_last and it == n - 1) and not (n % 2 == 0 and it == n - 1)
         if skip and skip_ready is not None and not waited:
@@ -505,8 +506,10 @@ def cbca_prog_chain(vol, tmp, support, prog, D, iterations, distance_threshold, 
             waited = True
         fn, who = ((lib.mccnn_cbca_iter_prog_skip, "mccnn_cbca_iter_prog_skip") if skip
                    else (lib.mccnn_cbca_iter_prog, "mccnn_cbca_iter_prog"))
+        timer.start("cbca_iter_prog_skip" if skip else "cbca_iter_prog")
         hip.check(fn(hip.ptr(src), hip.ptr(dst), hip.ptr(support), hip.ptr(prog), int(D), H, W, int(distance_threshold),
                      hip.stream()), who)
+        timer.stop()
         src, dst = dst, src
     return src, dst
 
@@ -577,7 +580,9 @@ def sgm_average_hwd(image_left, image_right, vols_hwd, sides, D, sgm_P1, sgm_P2,
     p1v = _f32(sgm_P1 / sgm_V)  # Python double division, rounded once (pf:204)
     p2, q1, q2, thr = _f32(sgm_P2), _f32(sgm_Q1), _f32(sgm_Q2), _f32(sgm_D)
     for r in SGM_DIRECTIONS:
-        timer.start("sgm_pass")
+        # (a launch that advances ONE volume - the free-running chains of StereoMatcher - is priced apart from the
+        # two-volume launch: half the bytes, and it runs beside whatever the other volume's chain is doing)
+        timer.start("sgm_pass" if len(vols_hwd) == 2 else "sgm_pass_one_volume")
         sgm_pass_hwd(image_left, image_right, vols_hwd, sides, D, r, p1h if r[0] == 0 else p1v, p2, q1, q2, thr,
                      scratch)
         timer.stop()
@@ -749,7 +754,7 @@ class StereoMatcher(object):
     def __init__(self, net, hp=None, cv_mode=hip.MCCNN_CV_EXACT, cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER,
                  feature_tile_rows=None, extras=None, features="auto", layout="auto", cbca_kernel="auto",
                  on_saturation="fallback", skip_unit_regions=True, two_chains=True, one_launch_builder=True,
-                 side_early=False, free_chains=False):
+                 side_early=False, free_chains=True):
         self.device = hip.require_device()
         self.net = net
         self.hp = dict(DEFAULT_HP)
@@ -793,10 +798,10 @@ class StereoMatcher(object):
         # two launches, the skip programs beside the first aggregation (A/B measurements)
         self.one_launch_builder = bool(one_launch_builder)
         # options measured with tools/dev_ab_matchers.py (profiles/r05_ab_matcher_options.txt): side_early - the side
-        # stream's work beside the conv stack instead of beside the cost volume (+0.04 ms: worse); free_chains - each
-        # volume's aggregation -> SGM -> aggregation as ONE free-running chain of one-volume launches, no join between
-        # the stages (-0.10 ms, same bits; opt-in because the SGM passes then run as one-volume launches beside whatever
-        # the other chain is doing, which no per-kernel figure describes)
+        # stream's work beside the conv stack instead of beside the cost volume (+0.04 ms: worse); free_chains (default
+        # since round 6) - each volume's aggregation -> SGM -> aggregation as ONE free-running chain of one-volume
+        # launches on its own stream, no join between the stages (-0.10 .. -0.16 ms per cfg2 pair, same bits); False =
+        # round 5's schedule: the chains join after every stage and the SGM passes are two-volume launches
         self.side_early = bool(side_early)
         self.free_chains = bool(free_chains)
         # opt-in departures from the reference (they change the output): the paper's rules it leaves out, and the
@@ -989,7 +994,10 @@ class StereoMatcher(object):
                                       skip_unit_regions=self.skip_unit_regions,
                                       right_stream=self._right_stream() if self.two_chains else None, **kw)
 
-            free = (self.free_chains and overlap and keep is None and progs is not None and self.two_chains)
+            # free-running chains (default): each volume's aggregation -> SGM -> aggregation is ONE chain of one-volume
+            # launches on its own stream; the two chains meet again only in front of the WTA-carrying last launch.  (With
+            # `keep` the stages are joined, so that both volumes of a stage can be handed out.)
+            free = (self.free_chains and keep is None and progs is not None and self.two_chains)
             if free:
                 n1, n2 = int(hp["cbca_num_iterations1"]), int(hp["cbca_num_iterations2"])
                 fuse = n2 >= 1 and D <= cbca_hwd_wta_max_d()
@@ -1001,41 +1009,53 @@ class StereoMatcher(object):
                 for st, v, t, sup, prog, side, scr in ((main_s, lh, as_hwd(b0), sup_l, progs[0], sides[0], ws["scratch"]),
                                                        (right_s, rh, as_hwd(b1), sup_r, progs[1], sides[1], ws["scratch2"])):
                     with torch.cuda.stream(st):
+                        # (the brackets are recorded on the chain's own stream: a stage's span beside the other chain)
+                        timer.span_start("aggregation_1")
                         v, t = cbca_prog_chain(v, t, sup, prog, D, n1, hp["cbca_distance"],
-                                               skip_unit_regions=self.skip_unit_regions, skip_ready=skip_ready)
+                                               skip_unit_regions=self.skip_unit_regions,
+                                               skip_ready=skip_ready if overlap else None, timer=timer)
+                        timer.span_stop("aggregation_1")
+                        timer.span_start("sgm")
                         sgm_average_hwd(L, R, [v], [side], D, hp["sgm_P1"], hp["sgm_P2"], hp["sgm_Q1"], hp["sgm_Q2"],
                                         hp["sgm_D"], hp["sgm_V"], scr, timer)
+                        timer.span_stop("sgm")
+                        timer.span_start("aggregation_2")
                         v, t = cbca_prog_chain(v, t, sup, prog, D, n2 - 1 if fuse else n2, hp["cbca_distance"], total=n2,
                                                fused_last=fuse, skip_unit_regions=self.skip_unit_regions,
-                                               skip_ready=skip_ready)
+                                               skip_ready=skip_ready if overlap else None, timer=timer)
+                        timer.span_stop("aggregation_2")
                         ends.append((v, t))
                 main_s.wait_stream(right_s)
                 (lh, lt), (rh, rt) = ends
                 if fuse:
+                    timer.start("cbca_iter_prog_pair")
                     hip.check(hip.load().mccnn_cbca_iter_prog_pair_wta(
                         hip.ptr(lh), hip.ptr(lt), hip.ptr(sup_l), hip.ptr(progs[0]), hip.ptr(rh), hip.ptr(rt), hip.ptr(sup_r),
                         hip.ptr(progs[1]), int(D), H, W, int(hp["cbca_distance"]), hip.ptr(m[0]), hip.ptr(m[1]), 0,
                         hip.stream()), "mccnn_cbca_iter_prog_pair_wta")
+                    timer.stop()
                     lh, lt, rh, rt = lt, lh, rt, rh
-            timer.span_start("aggregation_1")
             if not free:
+                timer.span_start("aggregation_1")
                 (lh, lt), (rh, rt) = aggregate_hwd(lh, as_hwd(b0), rh, as_hwd(b1), hp["cbca_num_iterations1"])
-            timer.span_stop("aggregation_1")
+                timer.span_stop("aggregation_1")
             if keep is not None:
                 keep["cbca1"] = (hwd_to_dhw(lh, D), hwd_to_dhw(rh, D))
             if not free:
+                timer.span_start("sgm")
                 sgm_average_hwd(L, R, [lh, rh], sides, D, hp["sgm_P1"], hp["sgm_P2"], hp["sgm_Q1"], hp["sgm_Q2"],
                                 hp["sgm_D"], hp["sgm_V"], ws["scratch"], timer)
+                timer.span_stop("sgm")
             if keep is not None:
                 keep["sgm"] = (hwd_to_dhw(lh, D), hwd_to_dhw(rh, D))
             # the last iteration carries the WTA of both results (and leaves the right volume, which nothing else
             # reads, unwritten) when a wave holds all disparities of a pixel
             fuse = int(hp["cbca_num_iterations2"]) >= 1 and D <= cbca_hwd_wta_max_d()
-            timer.span_start("aggregation_2")
             if not free:
+                timer.span_start("aggregation_2")
                 (lh, lt), (rh, rt) = aggregate_hwd(lh, lt, rh, rt, hp["cbca_num_iterations2"],
                                                    wta_out=(m[0], m[1]) if fuse else None, store_right=keep is not None)
-            timer.span_stop("aggregation_2")
+                timer.span_stop("aggregation_2")
             if overlap and skip_ready is not None:
                 torch.cuda.current_stream().wait_event(skip_ready)      # joins the side stream whatever the iteration count
             if keep is not None:

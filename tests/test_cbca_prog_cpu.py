@@ -19,6 +19,7 @@ import cbca_prog_ref as ref          # noqa: E402
 import asm_sim                       # noqa: E402
 import oracle as o                   # noqa: E402
 import synthetic                     # noqa: E402
+from helpers import assert_bits_strict  # noqa: E402
 
 LLVM = "/opt/rocm/lib/llvm/bin"
 
@@ -181,7 +182,7 @@ def test_generated_kernel_reproduces_the_oracle_in_the_simulator(vpl, w, nb, H, 
     img, vol = make_case(H, W, D, seed, flat)
     got, st = simulate(g, L, img, vol)
     want = oracle_cbca(img, vol)
-    assert np.array_equal(got, want, equal_nan=True), "max diff %g" % np.nanmax(np.abs(got - want))
+    assert_bits_strict(got, want, "simulated kernel against the oracle")
 
 
 @pytest.mark.parametrize("vpl,w,k,H,W,D,seed,flat", [(4, 20, 4, 12, 17, 8, 0, False), (4, 12, 2, 14, 23, 5, 1, False),
@@ -202,7 +203,7 @@ def test_skip_kernel_leaves_unit_regions_alone_and_equals_the_oracle_in_the_simu
     assert flat or unit.any()
     assert np.array_equal(v3[:, unit], v2[:, unit]) and np.array_equal(v2[:, unit], v1[:, unit])     # the fixed point
     got, _ = simulate(g, L, img, v2, out_init=v1)          # iteration 3 writes into the buffer iteration 1 wrote
-    assert np.array_equal(got, v3, equal_nan=True)
+    assert_bits_strict(got, v3, "skip kernel in the simulator against the oracle's third iteration")
     untouched, _ = simulate(g, L, img, v2)                 # nothing pre-filled: unit regions stay NaN
     assert np.isnan(untouched[:, unit]).all() and np.array_equal(untouched[:, ~unit], v3[:, ~unit])
 
@@ -282,7 +283,7 @@ def test_generated_kernel_with_early_first_op_in_the_simulator(skip):
         v1 = oracle_cbca(img, vol0)
         v2 = oracle_cbca(img, v1)
         got, _ = simulate(g, L, img, v2, out_init=v1)
-        assert np.array_equal(got, oracle_cbca(img, v2), equal_nan=True)
+        assert_bits_strict(got, oracle_cbca(img, v2), "early-dispatch skip kernel against the oracle")
 
 
 def test_generated_kernel_with_scalar_prefetch_in_the_simulator():

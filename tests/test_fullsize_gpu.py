@@ -16,7 +16,7 @@ import torch
 import tolerances as tol
 
 from conftest import ROOT
-from helpers import assert_bits
+from helpers import assert_bits, bits_strict, module_setting
 
 pytestmark = pytest.mark.gpu
 
@@ -45,7 +45,10 @@ def _stagewise(keep, L, R, D, o, exact):
 
     def diff(a, b):
         a = a.cpu().numpy() if torch.is_tensor(a) else a
-        return 0.0 if np.array_equal(a, b, equal_nan=True) else float(np.nanmax(np.abs(a.astype(np.float64) - b)))
+        if bits_strict(a, b):
+            return 0.0
+        m = float(np.nanmax(np.abs(a.astype(np.float64) - b)))
+        return m if m > 0.0 else float(np.spacing(np.float32(0)))     # a zero of the other sign: not 'all bits equal'
 
     cv = [t.cpu().numpy() for t in keep["cv"]]
     c1 = o.cost_volume_aggregation(L, R, cv[0], cv[1], hp["tau"], hp["dist"], 2)
@@ -252,15 +255,12 @@ def test_cfg3_width_oracle_window():
     vl = (-rng.random((D, H, W), dtype=np.float32)).astype(np.float32)
     vr = (-rng.random((D, H, W), dtype=np.float32)).astype(np.float32)
     ol, orr = o.cost_volume_aggregation(L, R, vl, vr, 0.02, 14, 2)
-    pf.CBCA_ORDER = "reference"
-    gl, gr = pf.cost_volume_aggregation(L, R, vl, vr, 0.02, 14, 2)
+    with module_setting(pf, "CBCA_ORDER", "reference"):
+        gl, gr = pf.cost_volume_aggregation(L, R, vl, vr, 0.02, 14, 2)
     assert_bits(gl, ol, "cbca reference order, W=1242")
     assert_bits(gr, orr, "cbca reference order, W=1242 (right)")
-    pf.CBCA_ORDER = "separable"
-    try:
+    with module_setting(pf, "CBCA_ORDER", "separable"):
         sl, sr = pf.cost_volume_aggregation(L, R, vl, vr, 0.02, 14, 2)
-    finally:
-        pf.CBCA_ORDER = "reference"
     assert max(np.abs(sl - ol).max(), np.abs(sr - orr).max()) <= 2 * 8 * float(np.spacing(np.float32(1.0)))
     a = o.SGM_average(ol.copy(), orr.copy(), L, R, 2.3, 55.9, 4, 8, 0.08, 1.5)
     b = pf.SGM_average(ol.copy(), orr.copy(), L, R, 2.3, 55.9, 4, 8, 0.08, 1.5)
@@ -273,8 +273,10 @@ def test_cfg3_width_oracle_window():
 
 
 @pytest.mark.parametrize("H,W,D,kernel", [(24, 750, 256, "prog"), (20, 1242, 192, "prog"), (12, 1500, 400, "prog"),
-                                          (20, 1242, 192, "hwd")],
+                                          (24, 750, 256, "prog_chains"), (20, 1242, 192, "prog_chains"),
+                                          (12, 1500, 400, "prog_chains"), (20, 1242, 192, "hwd")],
                          ids=["cfg2_width_and_disparities", "cfg3_width_and_disparities", "cfg4_width_and_disparities",
+                              "cfg2_one_volume_chains", "cfg3_one_volume_chains", "cfg4_one_volume_chains",
                               "cfg3_width_cbca_hwd_fallback"])
 def test_oracle_windows_at_real_width_and_disparity_range(H, W, D, kernel):
     """The SHIPPED default kernels against the CPU checker at the REAL width and the REAL disparity range of cfg2 / cfg3 /
@@ -285,7 +287,9 @@ def test_oracle_windows_at_real_width_and_disparity_range(H, W, D, kernel):
     launches followed by mccnn_cbca_iter_prog_pair_wta where one chunk holds D) - v4 kernels at 750x256, v3 at 1242x192,
     v4 with two chunks (and WTA as its own launch) at 1500x400; one case keeps cbca_hwd_kernel, the fallback for images
     wider than a program op can index (W > 2180).  The heights sit below / at the arm limit so the vertical arms clip at
-    both borders."""
+    both borders.  The `*_one_volume_chains` cases run the launches a pair really issues since round 5: the ONE-volume
+    entry points mccnn_cbca_iter_prog / mccnn_cbca_iter_prog_skip, the left chain on the current stream, the right one on
+    a second stream (34 of a pair's 35 aggregation launches), straight against the CPU checker."""
     import oracle as o
     import stereo_device as sd
     import synthetic
@@ -305,13 +309,14 @@ def test_oracle_windows_at_real_width_and_disparity_range(H, W, D, kernel):
     sl, sr = sd.cross_arms_pair(l, r, 0.02, 14)
     words = sl.cpu().numpy().view(np.uint32).reshape(-1)[:H * W]
     assert ((words & 0xfffff) == 0).any() and not ((words & 0xfffff) == 0).all()      # the skip launches have work to skip
-    if kernel == "prog":
+    if kernel in ("prog", "prog_chains"):
         progs = sd.cbca_prog_buffers(D, H, W, l.device)
         assert progs is not None
         sd.cbca_prog_build_pair(sl, sr, D, 14, progs)
+        chains = dict(right_stream=sd.right_stream(l.device)) if kernel == "prog_chains" else {}
 
         def aggregate(a, ta, b, tb, n, **kw):
-            return sd.cbca_prog_pair(a, ta, sl, b, tb, sr, progs, D, n, 14, **kw)
+            return sd.cbca_prog_pair(a, ta, sl, b, tb, sr, progs, D, n, 14, **dict(kw, **chains))
     else:
         def aggregate(a, ta, b, tb, n, **kw):
             return sd.cbca_hwd_pair(a, ta, sl, b, tb, sr, D, n, 14, **kw)

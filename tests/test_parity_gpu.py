@@ -16,7 +16,7 @@ import torch
 
 import tolerances as tol
 
-from helpers import assert_bits, bits_equal, hp_of
+from helpers import assert_bits, bits_equal, hp_of, module_setting
 
 pytestmark = pytest.mark.gpu
 
@@ -82,8 +82,7 @@ def test_golden_cross_region(pf, sd, golden_cases):
 def test_golden_cbca_reference_order_bit_exact(pf, golden_cases, order):
     """Both kernels that keep the reference's summation order: the pixel-major one behind the drop-in default and the
     plane-major one (round 2; still what distances > 14 use)."""
-    pf.CBCA_ORDER = order
-    try:
+    with module_setting(pf, "CBCA_ORDER", order):
         for name, g in golden_cases:
             hp = hp_of(g)
             tau, dist = hp["cbca_intensity"], hp["cbca_distance"]
@@ -98,12 +97,14 @@ def test_golden_cbca_reference_order_bit_exact(pf, golden_cases, order):
             l, r = pf.cost_volume_aggregation(g["left"], g["right"], g["sgm_l"], g["sgm_r"], tau, dist, hp["it2"])
             assert_bits(l, g["cbca2_l"], name)
             assert_bits(r, g["cbca2_r"], name)
-    finally:
-        pf.CBCA_ORDER = "separable"
 
 
 def test_golden_cbca_separable_tolerance(pf, golden_cases):
-    pf.CBCA_ORDER = "separable"
+    with module_setting(pf, "CBCA_ORDER", "separable"):
+        _golden_cbca_separable_tolerance(pf, golden_cases)
+
+
+def _golden_cbca_separable_tolerance(pf, golden_cases):
     for name, g in golden_cases:
         hp = hp_of(g)
         tau, dist = hp["cbca_intensity"], hp["cbca_distance"]
@@ -257,14 +258,12 @@ def test_oracle_cbca_and_cross(pf, sd, H, W, D):
     assert cnt_o.max() > 30, "test image must have non-trivial support regions"
     vl, vr = _rand_vol(rng, D, H, W), _rand_vol(rng, D, H, W)
     ol, orr = o.cost_volume_aggregation(L, R, vl, vr, 0.02, 14, 3)
-    pf.CBCA_ORDER = "reference"
-    try:
+    with module_setting(pf, "CBCA_ORDER", "reference"):
         gl, gr = pf.cost_volume_aggregation(L, R, vl, vr, 0.02, 14, 3)
-    finally:
-        pf.CBCA_ORDER = "separable"
     assert_bits(gl, ol, "cbca reference order L")
     assert_bits(gr, orr, "cbca reference order R")
-    sl, sr = pf.cost_volume_aggregation(L, R, vl, vr, 0.02, 14, 3)
+    with module_setting(pf, "CBCA_ORDER", "separable"):
+        sl, sr = pf.cost_volume_aggregation(L, R, vl, vr, 0.02, 14, 3)
     assert np.abs(sl - ol).max() <= 3e-6 and np.abs(sr - orr).max() <= 3e-6
 
 
@@ -279,14 +278,12 @@ def test_oracle_cbca_long_arms_other_distance(pf):
     vl, vr = _rand_vol(rng, D, H, W), _rand_vol(rng, D, H, W)
     for dist in (14, 6, 20):
         ol, orr = o.cost_volume_aggregation(L, R, vl, vr, 0.02, dist, 2)
-        pf.CBCA_ORDER = "reference"
-        try:
+        with module_setting(pf, "CBCA_ORDER", "reference"):
             gl, gr = pf.cost_volume_aggregation(L, R, vl, vr, 0.02, dist, 2)
-        finally:
-            pf.CBCA_ORDER = "separable"
         assert_bits(gl, ol, "flat image, distance %d" % dist)
         assert_bits(gr, orr, "striped image, distance %d" % dist)
-        sl, _ = pf.cost_volume_aggregation(L, R, vl, vr, 0.02, dist, 2)
+        with module_setting(pf, "CBCA_ORDER", "separable"):
+            sl, _ = pf.cost_volume_aggregation(L, R, vl, vr, 0.02, dist, 2)
         assert np.abs(sl - ol).max() <= 2e-5   # up to (2*19+1)^2 terms per sum here
 
 
@@ -616,14 +613,12 @@ def test_oracle_random_shapes_fast_and_exact_kernels(pf, sd, H, W, D):
     assert np.abs(ml - ol).max() <= 2e-6 and np.abs(mr - orr).max() <= 2e-6, (H, W, D)
     # aggregation: reference order bit-exact, streaming kernel within the stated tolerance
     cl, cr = o.cost_volume_aggregation(L, R, ol, orr, 0.02, 14, 2)
-    pf.CBCA_ORDER = "reference"
-    try:
+    with module_setting(pf, "CBCA_ORDER", "reference"):
         rl, rr = pf.cost_volume_aggregation(L, R, ol, orr, 0.02, 14, 2)
-    finally:
-        pf.CBCA_ORDER = "separable"
     assert_bits(rl, cl, "cbca reference order L %dx%dx%d" % (H, W, D))
     assert_bits(rr, cr, "cbca reference order R %dx%dx%d" % (H, W, D))
-    sl, sr = pf.cost_volume_aggregation(L, R, ol, orr, 0.02, 14, 2)
+    with module_setting(pf, "CBCA_ORDER", "separable"):
+        sl, sr = pf.cost_volume_aggregation(L, R, ol, orr, 0.02, 14, 2)
     assert np.abs(sl - cl).max() <= 2e-6 and np.abs(sr - cr).max() <= 2e-6, (H, W, D)
     # SGM_average (fused first pass when D <= 256) is bit-exact
     if D >= 2:

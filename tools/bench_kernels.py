@@ -79,6 +79,9 @@ def main():
     for name, r in (("sgm_pass_h", (0, 1)), ("sgm_pass_v", (1, 0))):
         add(name, lambda r=r: sd.sgm_pass_hwd(dl, dr, [hwd, hwd2], [0, 1], D, r, 2.3, 55.9, 4.0, 8.0, 0.08, scratch),
             4 * vol_bytes)
+    # one volume per launch: what the free-running chains of StereoMatcher issue (each chain on its own stream), alone here
+    for name, r in (("sgm_pass_one_volume_h", (0, 1)), ("sgm_pass_one_volume_v", (1, 0))):
+        add(name, lambda r=r: sd.sgm_pass_hwd(dl, dr, [hwd], [0], D, r, 2.3, 55.9, 4.0, 8.0, 0.08, scratch), 2 * vol_bytes)
     if D <= sd.SGM_FIRST_PASS_MAX_D:
         import ctypes
 
