@@ -10,9 +10,11 @@
 //
 // The assembled code objects are embedded in this library (build/asm/cbca_prog_v{2,3,4}.inc, Makefile) and loaded
 // through the HIP module API on first use, once per device.
+#include <algorithm>
 #include <iterator>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 #include "cbca_prog_build.h"
 #include "cbca_prog_layout_v2.h"
@@ -235,10 +237,12 @@ struct Shape {
 struct Built {
     int D, H, W;
     const void *support;
-    unsigned long long gen;
+    unsigned long long gen;       // generation of the support arms the programs were built from
+    unsigned long long used;      // last build or successful look-up (eviction is least-recently-used)
 };
 static std::unordered_map<const void *, Built> g_built[2];      // [0] the full programs, [1] the skip programs
 static std::mutex g_built_mu;
+static unsigned long long g_built_tick = 0;
 
 static int check_built(const void *prog, const mccnn_support_t *support, int D, int H, int W, int set)
 {
@@ -247,7 +251,8 @@ static int check_built(const void *prog, const mccnn_support_t *support, int D, 
     MCCNN_REQUIRE(it != g_built[set].end(), MCCNN_E_INVALID,
                   "mccnn_cbca_iter_prog_pair: this program buffer has not been written by mccnn_cbca_prog_build_%spair",
                   set ? "skip_" : "");
-    const Built &b = it->second;
+    Built &b = it->second;
+    b.used = ++g_built_tick;
     MCCNN_REQUIRE(b.D == D && b.H == H && b.W == W, MCCNN_E_INVALID,
                   "mccnn_cbca_iter_prog_pair: programs were built for %dx%dx%d, called with %dx%dx%d", b.W, b.H, b.D, W, H, D);
     MCCNN_REQUIRE(b.support == support && b.gen == support_generation(support), MCCNN_E_INVALID,
@@ -325,14 +330,18 @@ static int prog_build(const char *who, int mode, const mccnn_support_t *support_
         const unsigned long long gl = support_generation(support_left), gr = support_generation(support_right);
         std::lock_guard<std::mutex> lock(prog::g_built_mu);
         auto &reg = prog::g_built[set];
-        // bounded like the support registry: past 4096 entries the ones built from the oldest support arms go (their
-        // generations are 2048+ mccnn_cross_arms calls behind: such programs are stale or their buffers long freed)
+        // bounded like the support registry: past 4096 entries the least recently used half goes (a look-up by an
+        // aggregation launch refreshes an entry, so program buffers that are in use stay)
         if (reg.size() > 4096) {
-            const unsigned long long newest = gl > gr ? gl : gr, keep_from = newest > 2048 ? newest - 2048 : 0;
-            for (auto it = reg.begin(); it != reg.end();) it = it->second.gen <= keep_from ? reg.erase(it) : std::next(it);
+            std::vector<unsigned long long> used;
+            used.reserve(reg.size());
+            for (const auto &kv : reg) used.push_back(kv.second.used);
+            std::nth_element(used.begin(), used.begin() + used.size() / 2, used.end());
+            const unsigned long long keep_from = used[used.size() / 2];
+            for (auto it = reg.begin(); it != reg.end();) it = it->second.used < keep_from ? reg.erase(it) : std::next(it);
         }
-        reg[prog_left] = prog::Built{D, H, W, support_left, gl};
-        reg[prog_right] = prog::Built{D, H, W, support_right, gr};
+        reg[prog_left] = prog::Built{D, H, W, support_left, gl, ++prog::g_built_tick};
+        reg[prog_right] = prog::Built{D, H, W, support_right, gr, ++prog::g_built_tick};
     }
     return rc;
 }

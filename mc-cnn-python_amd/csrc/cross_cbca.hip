@@ -15,9 +15,11 @@
 //                       bit-exact; its separable variant serves distances > 14.
 #include <math.h>
 
+#include <algorithm>
 #include <iterator>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 #include "support.h"
 
@@ -896,10 +898,13 @@ static int launch_cbca_stream(const StreamJobs &jobs, int D, int H, int W, hipSt
 // kernel and its halo).  Pointers it has never seen (e.g. a device-side copy) pass: the kernels are memory-safe for
 // any arms (clamped above / baked within range), only the sums would be those of the clamped region.
 namespace {
-struct SupportInfo { int H, W, L; unsigned long long gen; };
+// gen: when the arms were written (what was derived from a buffer can tell if it is stale); used: the last time an entry
+// point looked the buffer up - eviction goes by `used`, so a long-lived buffer that is in use is never dropped
+struct SupportInfo { int H, W, L; unsigned long long gen; unsigned long long used; };
 std::mutex g_support_mu;
 std::unordered_map<const void *, SupportInfo> g_support;
-unsigned long long g_support_gen = 0;     // counts mccnn_cross_arms calls: what was derived from a buffer can tell if it is stale
+unsigned long long g_support_gen = 0;     // counts the buffers mccnn_cross_arms has written (two per pair call)
+unsigned long long g_support_tick = 0;    // counts registrations and look-ups
 }  // namespace
 
 unsigned long long mccnn::support_generation(const mccnn_support_t *support)
@@ -913,6 +918,7 @@ int mccnn::check_support_record(const mccnn_support_t *support, int H, int W, in
 {
     std::lock_guard<std::mutex> lock(g_support_mu);
     const auto it = g_support.find(support);
+    if (it != g_support.end()) it->second.used = ++g_support_tick;
     MCCNN_REQUIRE(!must_be_known || it != g_support.end(), MCCNN_E_INVALID,
                   "%s: `support` is not a buffer mccnn_cross_arms has written (the kernel also reads the planes behind "
                   "plane 0: pass the whole mccnn_support_bytes(H, W) buffer, not a copy of its first plane)", who);
@@ -942,15 +948,19 @@ static int launch_cross_arms(const float *img0, const float *img1, mccnn_support
     if (rc == 0) {
         std::lock_guard<std::mutex> lock(g_support_mu);
         // The registry is authoritative (the *_hwd / *_prog entry points refuse buffers it does not know), so it is never
-        // emptied: when it outgrows its bound only the OLDEST half goes - buffers whose arms were written 2048+
-        // mccnn_cross_arms calls ago (long freed, or due for a rewrite before their next use anyway).
+        // emptied: when it outgrows its bound the LEAST RECENTLY USED half goes (every look-up by an entry point
+        // refreshes an entry, so a buffer that is still being aggregated with stays however old its arms are).
         if (g_support.size() > 4096) {
-            const unsigned long long keep_from = g_support_gen > 2048 ? g_support_gen - 2048 : 0;
+            std::vector<unsigned long long> used;
+            used.reserve(g_support.size());
+            for (const auto &kv : g_support) used.push_back(kv.second.used);
+            std::nth_element(used.begin(), used.begin() + used.size() / 2, used.end());
+            const unsigned long long keep_from = used[used.size() / 2];
             for (auto it = g_support.begin(); it != g_support.end();)
-                it = it->second.gen <= keep_from ? g_support.erase(it) : std::next(it);
+                it = it->second.used < keep_from ? g_support.erase(it) : std::next(it);
         }
-        g_support[sup0] = SupportInfo{H, W, L, ++g_support_gen};
-        g_support[sup1] = SupportInfo{H, W, L, ++g_support_gen};
+        g_support[sup0] = SupportInfo{H, W, L, ++g_support_gen, ++g_support_tick};
+        g_support[sup1] = SupportInfo{H, W, L, ++g_support_gen, ++g_support_tick};
     }
     return rc;
 }

@@ -289,3 +289,40 @@ def test_cost_volume_pixel_major_abi_errors(sd):
         == hip.MCCNN_E_UNSUPPORTED
     assert lib.mccnn_cost_volume_hwd(None, hip.ptr(f), 4, 40, 64, 8, hip.ptr(o), hip.ptr(o), hip.MCCNN_CV_EXACT, st) \
         == hip.MCCNN_E_INVALID
+
+
+@pytest.mark.parametrize("H,W,D", [(12, 90, 64), (9, 300, 256), (6, 77, 40)])
+def test_cost_volume_border_fill_special_values_against_the_oracle(sd, H, W, D):
+    """pf:94-95 / 105-106 (the 3-tap border recurrences) on scores that are subnormal, +-0, +-inf, NaN, next to FLT_MIN and
+    next to FLT_MAX: the fill's three-operation replacement of `s / 3.f` (cost_volume.hip, `third`; exhaustively
+    checked on x86 by tools/probe/div3_exhaustive.c) runs here on the device - float32 denormals on, no contraction
+    (-ffp-contract=off in the Makefile) - and must give the checker's bits, signs of zeros included.  The features
+    have one non-zero channel, so a score is minus ONE exact product and every special value is placed at will."""
+    import oracle as o
+    from helpers import assert_bits_strict
+    rng = np.random.default_rng(H * W + D)
+    mags = np.array([0.0, -0.0, 1e-22, 1e-20, 3e-20, 1e-19, 1.0, -1.0, 0.75, 1e18, 1.8e19, -1.8e19, 2.5e19,
+                     np.inf, -np.inf, np.nan], np.float32)
+
+    def feats(special_rate):
+        f = np.zeros((H, W, 64), np.float32)
+        m = rng.standard_normal((H, W)).astype(np.float32)
+        hit = rng.random((H, W)) < special_rate
+        m[hit] = mags[rng.integers(0, mags.size, int(hit.sum()))]
+        f[:, :, 0] = m
+        return f
+    # rows 0..: mostly ordinary values with specials sprinkled in; last rows: specials everywhere
+    fl, fr = feats(0.15), feats(0.15)
+    fl[-2:], fr[-2:] = feats(1.0)[-2:], feats(1.0)[-2:]
+    with np.errstate(all="ignore"):
+        ol, orr = o.compute_cost_volume(fl, fr, D)
+    assert np.isnan(ol).any() and np.isinf(ol).any()
+    tiny = np.abs(ol[np.isfinite(ol) & (ol != 0)])
+    assert (tiny < 1.2e-38).any() and (tiny > 1e38).any()                  # subnormal and near-FLT_MAX entries exist
+    gl, gr = sd.cost_volume_hwd(dev(fl), dev(fr), D)
+    assert_bits_strict(sd.hwd_to_dhw(gl, D).cpu().numpy(), ol, "cost volume + border fill, special values (left)")
+    assert_bits_strict(sd.hwd_to_dhw(gr, D).cpu().numpy(), orr, "cost volume + border fill, special values (right)")
+    # the plane-major form of the same stage (process_functional's boundary)
+    pl, pr = sd.cost_volume(dev(fl), dev(fr), D)
+    assert_bits_strict(pl.cpu().numpy(), ol, "plane-major cost volume, special values (left)")
+    assert_bits_strict(pr.cpu().numpy(), orr, "plane-major cost volume, special values (right)")
