@@ -8,8 +8,9 @@
 // The score matrix of one image row, S[w,w'] = <fl[w], fr[w']>, is a banded product (0 <= w-w' < D); every
 // entry feeds lcv[d,h,w] and rcv[d,h,w'] (d = w-w'), both contiguous in w for fixed d, so a workgroup that owns
 // 64 columns x 64 disparities of one row writes 256-B runs into both volumes.  Bound: HBM writes (8 B/voxel for
-// 128 flop/voxel).  The recurrences run on the already negated values: the mean is linear and rounding is
-// sign-symmetric, so the bits equal the reference's fill-then-negate.
+// 128 flop/voxel).  The recurrences run on the already negated values: rounding is sign-symmetric, so
+// -((0 - x1 - x2 - x3) / 3) on them has the bits of the reference's fill-then-negate, the sign of an exactly-zero sum
+// included (round 6: a plain 0 + x1 + x2 + x3 gave +0.0 there where the reference has -0.0).
 //
 // MCCNN_CV_EXACT  : VALU kernel that reproduces NumPy's float32 pairwise summation of the 64 products
 //                   (8 running sums, fixed combine tree - numpy loops_utils pairwise_sum) bit for bit.
@@ -526,10 +527,12 @@ __global__ __launch_bounds__(64) void cost_volume_fill_kernel(float *__restrict_
         for (int wtop = d - 1; wtop >= 0; wtop -= 64) {
             const int cnt = min(64, wtop + 1);
             for (int j = 0; j < cnt; ++j) {
-                float s = 0.f + x1;
-                s = s + x2;
-                s = s + x3;
-                const float v = s / 3.f;
+                // (the reference sums BEFORE it negates, and NumPy's reduction starts from the identity +0: the sum of the
+                // reference's values is 0 - x1 - x2 - x3 on the negated ones - the same bits, a zero sum's sign included)
+                float s = 0.f - x1;
+                s = s - x2;
+                s = s - x3;
+                const float v = -(s / 3.f);
                 tile[lane * 65 + j] = v;
                 x3 = x2; x2 = x1; x1 = v;
             }
@@ -546,10 +549,12 @@ __global__ __launch_bounds__(64) void cost_volume_fill_kernel(float *__restrict_
         for (int wbot = W - d; wbot < W; wbot += 64) {
             const int cnt = min(64, W - wbot);
             for (int j = 0; j < cnt; ++j) {
-                float s = 0.f + x1;
-                s = s + x2;
-                s = s + x3;
-                const float v = s / 3.f;
+                // (the reference sums BEFORE it negates, and NumPy's reduction starts from the identity +0: the sum of the
+                // reference's values is 0 - x1 - x2 - x3 on the negated ones - the same bits, a zero sum's sign included)
+                float s = 0.f - x1;
+                s = s - x2;
+                s = s - x3;
+                const float v = -(s / 3.f);
                 tile[lane * 65 + j] = v;
                 x1 = x2; x2 = x3; x3 = v;
             }
@@ -615,10 +620,10 @@ __global__ __launch_bounds__(64) void cost_volume_fill_hwd_kernel(float *__restr
                 for (int i = 0; i < 4; ++i) {
                     const int d = dbase[g] + i;
                     const bool stored = left ? c >= d : c < W - d;     // the score itself (d >= D: pad, never used)
-                    float s = 0.f + x1[g][i];
-                    s = s + x2[g][i];
-                    s = s + x3[g][i];
-                    const float val = stored ? v[i] : s / 3.f;
+                    float s = 0.f - x1[g][i];     // the reference's (0 + x1 + x2 + x3) / 3 on its not yet negated values
+                    s = s - x2[g][i];
+                    s = s - x3[g][i];
+                    const float val = stored ? v[i] : -(s / 3.f);
                     any |= !stored && d < D;
                     if (left) { x3[g][i] = x2[g][i]; x2[g][i] = x1[g][i]; x1[g][i] = val; }     // x1 = column c + 1 next
                     else      { x1[g][i] = x2[g][i]; x2[g][i] = x3[g][i]; x3[g][i] = val; }     // x3 = column c - 1 next
@@ -680,10 +685,13 @@ __global__ __launch_bounds__(64) void cost_volume_fill_hwd_lanes_kernel(float *_
         return (__builtin_fabsf(s) < __builtin_inff() && s != 0.f) ? q2 : s;
     };
     auto step = [&](int c, bool stored, float have) {
-        float s = 0.f + x1;
-        s = s + x2;
-        s = s + x3;
-        const float val = stored ? have : third(s);
+        // the reference's (0 + x1 + x2 + x3) / 3 on its not yet negated values (pf:94-95 run before pf:111-112, and NumPy's
+        // reduction starts from the identity +0): 0 - x1 - x2 - x3 on the negated ones, negated again - the same bits as
+        // summing the stored values except that a sum that is exactly zero comes out as -0.0, like the reference's
+        float s = 0.f - x1;
+        s = s - x2;
+        s = s - x3;
+        const float val = stored ? have : -third(s);
         if (left) { x3 = x2; x2 = x1; x1 = val; }               // x1 = column c + 1 next
         else      { x1 = x2; x2 = x3; x3 = val; }               // x3 = column c - 1 next
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rs, stored ? kDrop : sto, (unsigned)c * pix, 0);
