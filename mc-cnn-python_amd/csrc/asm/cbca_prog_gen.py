@@ -125,8 +125,16 @@ def ins_size(i):
 
 class Params:
     def __init__(self, vpl=4, K=2, G=5, W=12, NB=1, PF=0, wta=False, debug=0, order=0, minvgpr=0, skip=False, ring=0, persist=False,
-                 pipe=0, ntload=False, early=False):
+                 pipe=0, ntload=False, early=False, tile=0):
         assert K in (1, 2, 4, 8), "anchor sets are aligned power-of-two groups of anchor rows"
+        # tile (round 6): a workgroup of `tile` waves owns `tile` horizontally adjacent patches and sweeps their region rows
+        # in lock step: a STEP op (every wave of the tile has the same ones at the same places) brings the union of the
+        # tile's horizontal arms in one region row into LDS ONCE - every wave requests its share with buffer_load ... lds,
+        # between two barriers - and the LOADL ops that follow copy a patch's window out of LDS into the register window
+        # (ds_read_b128), where the unchanged ADD lines find it.  The bytes through the vector memory pipe per anchor
+        # fall to (5 tile + 2 a) / (tile (5 + 2 a)) for arms of length a; the window loads become LDS reads.
+        self.tile = tile
+        assert not tile or not (pipe or ring or persist or NB != 1 or PF or early or ntload), "tile: the plain one-window kernel"
         # ntload: a second LOAD line (n <= G) whose loads carry the non-temporal hint: for region rows that consist of
         # unit-region pixels only (nobody else's region holds them, so keeping them in L2 only evicts lines that
         # neighbouring patches will read again)
@@ -185,6 +193,13 @@ class Params:
                 self.v_nextA, self.v_nextB = self.nvgpr, self.nvgpr + 1
                 self.nvgpr += 2
             self.nvgpr_alloc = max(self.nvgpr, minvgpr)
+        if tile:
+            self.SLOTS = tile * G + 2 * R                 # LDS slots of a region row: the tile's columns + both longest arms
+            self.SB = 256 * vpl                           # bytes of a slot (64 lanes x vpl floats)
+            assert self.SLOTS * self.SB <= 65536, "the LDS address of a slot travels in M0[15:0]"
+            self.v_lane16, self.v_lds = self.nvgpr, self.nvgpr + 1
+            self.nvgpr += 2
+            self.nvgpr_alloc = max(self.nvgpr, minvgpr)
 
     def acc(self, k, j, c=0):
         return (k * self.G + j) * self.RS + c
@@ -198,6 +213,8 @@ class Params:
         return out
 
     def name(self):
+        if self.tile:
+            return "mccnn_cbca_tile%d_v%d%s" % (self.tile, self.VPL, "_wta" if self.wta else "_skip" if self.skip else "")
         return "mccnn_cbca_prog_v%d%s%s" % (self.VPL, "p" if self.pipe else "", "_wta" if self.wta else "_skip" if self.skip else "")
 
 
@@ -232,6 +249,7 @@ S = dict(
     nwc=93, cg=94, z=95, rg=36, cg0=37, prg=38, guard=39, band=78, cgn=79,
     rs_pn=84,          # s[84:87] (persist): descriptor of the next patch's program
     pfa=100,           # s[100:101]
+    wave=90, st_n=91, st_lds=92, st_s=93, st_str=94,      # (tile) wave of the workgroup; STEP's loop state
 )
 NSGPR = 102
 
@@ -461,6 +479,11 @@ class Gen:
         e("s_load_dwordx8", s("Dp", 8), s("karg", 2), 0x40)
         if P.wta:
             e("s_load_dwordx8", s("disp", 8), s("karg", 2), 0x60)
+        if P.tile:            # v0 = work-item id of the workgroup: wave = v0 >> 6 (uniform), v0 = lane from here on
+            e("v_lshrrev_b32", vreg(P.v_lds), 6, "v0")
+            e("s_nop", 4, comment="gfx940+: a v_readlane / v_readfirstlane may not follow the VALU write of its source at once")
+            e("v_readfirstlane_b32", s("wave"), vreg(P.v_lds))
+            e("v_and_b32", "v0", 63, "v0")
         e("s_waitcnt", "lgkmcnt(0)")
         # y0 = (bx & 7) * band_rows + (bx >> 3) * K ; patch row group = (bx & 7) * band_groups + (bx >> 3)
         e("s_and_b32", s("t0"), s("bx"), 7)
@@ -470,6 +493,9 @@ class Gen:
         else:                 # ... row group by row group: x = (band, column group), y = row group
             e("s_lshr_b32", s("t3"), s("bx"), 3)
             e("s_mov_b32", s("t1"), s("by"))
+        if P.tile:            # the grid counts tiles: this wave's column group = tile * waves + wave (ngroups is padded to whole tiles)
+            e("s_mul_i32", s("t3"), s("t3"), P.tile)
+            e("s_add_u32", s("t3"), s("t3"), s("wave"))
         e("s_mul_i32", s("y0"), s("t0"), s("band_rows"))
         e("s_mul_i32", s("t2"), s("t1"), K)
         e("s_add_u32", s("y0"), s("y0"), s("t2"))
@@ -517,6 +543,8 @@ class Gen:
             e("v_lshlrev_b32", vreg(P.v_lane16), 4, "v0", comment="lane * 16: this lane's bytes of an LDS slot")
             e("s_mov_b32", s("ring_head"), 0)
             e("s_mov_b32", s("ring_tail"), 0)
+        if P.tile:
+            e("v_mul_u32_u24", vreg(P.v_lane16), 4 * VPL, "v0", comment="this lane's bytes of an LDS slot")
         # region sizes of the K x G anchors for the END handler (rows clamped to the image; words past the right edge are
         # never used), requested here so that they arrive under the program: the kernarg registers they land in are dead
         e("s_sub_u32", s("t3"), s("H"), 1)
@@ -638,7 +666,63 @@ class Gen:
                     e("s_sub_u32", s("so"), s("so"), s("pix"))
             self.label("load_done")
             self.tail()
-        for b in range(0 if P.pipe else P.NB):
+        if P.tile:
+            SB = P.SB
+            # ---- LOADL n: LDS slots p .. p + n - 1 (p = the parameter) -> window slots 0 .. n - 1 --------------------------
+            for n in range(1, W + 1):
+                self.label("loadl_n%d" % n)
+                e("s_lshr_b32", s("t0"), s("op"), 16)
+                e("s_mov_b32", "m0", s("safe_m0"), comment="index 0: the v_add below must read v_lane16 itself")
+                e("s_mul_i32", s("t0"), s("t0"), SB)
+                e("v_add_u32", vreg(P.v_lds), s("t0"), vreg(P.v_lane16))
+                if n != W:
+                    e("s_branch", "loadl_blk%d" % n)
+            rd = {1: "ds_read_b32", 2: "ds_read_b64", 3: "ds_read_b96", 4: "ds_read_b128"}[VPL]
+            for n in range(W, 0, -1):
+                self.label("loadl_blk%d" % n)
+                if not (P.debug & 64):                                   # debug 64 (fault hunting): no LDS reads
+                    e(rd, vreg(P.PHYS_WIN + P.RS * (n - 1), VPL), vreg(P.v_lds), offset=(n - 1) * SB)
+                else:
+                    e("s_nop", 0)
+                    e("s_nop", 0)
+            self.tail(wait="lgkmcnt(0)")
+            # ---- STEP nslots (parameter), p (the next program word: pixel index of LDS slot 0 relative to the patch's first
+            # region row): every wave of the workgroup arrives here at the same op of its own program.  Barrier (nobody
+            # reads the previous row any more: a LOADL waits for its reads before its arms run), this wave's share of the
+            # row - slots wave, wave + NW, .. - straight into LDS, wait, barrier.
+            self.label("step")
+            e("s_lshr_b32", s("st_n"), s("op"), 16)
+            e("v_readlane_b32", s("so"), vreg(P.v_progA), s("i"))
+            e("s_add_u32", s("i"), s("i"), 1)
+            e("s_add_u32", s("so"), s("so"), s("wave"))
+            e("s_mul_i32", s("so"), s("so"), s("pix"))
+            e("s_mul_i32", s("st_lds"), s("wave"), SB)
+            e("s_mul_i32", s("st_str"), s("pix"), P.tile)
+            e("s_mov_b32", s("st_s"), s("wave"))
+            e("s_set_gpr_idx_off")
+            e("s_barrier")
+            self.label("step_loop")
+            e("s_cmp_ge_u32", s("st_s"), s("st_n"))
+            e("s_cbranch_scc1", "step_done")
+            e("s_mov_b32", "m0", s("st_lds"))
+            op = {1: "buffer_load_dword", 2: "buffer_load_dwordx2", 3: "buffer_load_dwordx3", 4: "buffer_load_dwordx4"}[VPL]
+            if not (P.debug & 32):                                       # debug 32 (fault hunting): no requests
+                e(op, vreg(P.v_voff), s("rs_in", 4), s("so"), offen=True, lds=True)
+            else:
+                e("s_nop", 0)
+                e("s_nop", 0)
+            e("s_add_u32", s("st_s"), s("st_s"), P.tile)
+            e("s_add_u32", s("st_lds"), s("st_lds"), P.tile * SB)
+            e("s_add_u32", s("so"), s("so"), s("st_str"))
+            e("s_branch", "step_loop")
+            self.label("step_done")
+            e("s_waitcnt", "vmcnt(0)")
+            e("s_barrier")
+            e("s_mov_b32", "m0", s("safe_m0"))
+            e("s_set_gpr_idx_on", s("st_n"), "gpr_idx(SRC1)", comment="(the dispatcher sets M0 from the next op)")
+            e("s_mov_b32", "m0", s("safe_m0"))
+            self.tail()
+        for b in range(0 if (P.pipe or P.tile) else P.NB):
             for n in range(1, W + 1):
                 if b == 0 and n == 1:
                     self.label("h_load1")
@@ -810,6 +894,8 @@ class Gen:
                     self.label("nodiv_%d_%d" % (k, j))
         # stores: per anchor row a descriptor that ends with the row / the image (columns past the edge are dropped)
         e("s_sub_u32", s("t5"), s("W"), s("x0"))
+        if P.tile:
+            e("s_max_i32", s("t5"), s("t5"), 0, comment="a patch of the padded tile that lies right of the image stores nothing")
         e("s_min_i32", s("t5"), s("t5"), G)
         e("s_mul_i32", s("t5"), s("t5"), s("pix"), comment="bytes of the patch's columns inside the image")
         e("s_mov_b32", sreg(S["rs_out"] + 3), 0x00020000)
@@ -980,7 +1066,13 @@ class Gen:
         L = dict(VPL=P.VPL, RS=P.RS, K=P.K, G=P.G, W=P.W, MAXD=P.MAXD, MAXA=P.MAXA, R=R, NWAIT=P.NWAIT, BLK=4 * P.VPL // u,
                  M0_SRC1=M0_SRC1, code_bytes=o["__end"], nvgpr=P.nvgpr)
         L["add"] = {key: (o[name] - base) // u for key, name in self.lines.items()}
-        if P.pipe:
+        L["tile"] = P.tile
+        if P.tile:
+            L["load"] = [[0] + [-1] * P.W]
+            L["loadl"] = [0] + [(o["loadl_n%d" % n] - base) // u for n in range(1, P.W + 1)]
+            L["step"] = (o["step"] - base) // u
+            L["SLOTS"], L["SB"] = P.SLOTS, P.SB
+        elif P.pipe:
             L["load"] = [[0] + [-1] * P.W]
             L["loadk"] = [(o["loadk_%d" % k] - base) // u for k in range(P.W)]
         else:
@@ -1011,12 +1103,14 @@ class Gen:
             else:
                 line = i.render()
                 # local labels: branch targets and the code_base difference
-                line = re.sub(r"\b(code_base|after_getpc|done|pf_done|pf_loop\d+|load_b\d+_blk\d+|loadblk_\d+|loadnt_blk\d+|load_done|loadf_blk\d+|h_end|h_load1|h_loadf1|first_is_end|nodiv_\d+_\d+|nostore_\d+_\d+|pf_blk\d+|cp_blk\d+|p_div|p_divd|p_z|p_patch|p_nextz|e_nofetch)\b", lambda m: ".L%s_%s" % (name, m.group(1)), line)
+                line = re.sub(r"\b(code_base|after_getpc|done|pf_done|pf_loop\d+|load_b\d+_blk\d+|loadblk_\d+|loadnt_blk\d+|load_done|loadf_blk\d+|h_end|h_load1|h_loadf1|first_is_end|nodiv_\d+_\d+|nostore_\d+_\d+|pf_blk\d+|cp_blk\d+|loadl_blk\d+|step_loop|step_done|p_div|p_divd|p_z|p_patch|p_nextz|e_nofetch)\b", lambda m: ".L%s_%s" % (name, m.group(1)), line)
                 out.append(line)
         kargs = 0x80 if (P.wta or P.persist) else 0x60
+        lds_bytes = P.SLOTS * P.SB if P.tile else P.ring * 256 * P.VPL
+        wg = 64 * P.tile if P.tile else 64
         out += [".Lfunc_end_%s:" % name, ".size %s, .Lfunc_end_%s-%s" % (name, name, name), "",
                 ".rodata", ".p2align 6", ".amdhsa_kernel %s" % name,
-                "  .amdhsa_group_segment_fixed_size %d" % (P.ring * 256 * P.VPL), "  .amdhsa_private_segment_fixed_size 0",
+                "  .amdhsa_group_segment_fixed_size %d" % lds_bytes, "  .amdhsa_private_segment_fixed_size 0",
                 "  .amdhsa_kernarg_size %d" % kargs, "  .amdhsa_user_sgpr_count 2",
                 "  .amdhsa_user_sgpr_kernarg_segment_ptr 1", "  .amdhsa_system_sgpr_workgroup_id_x 1",
                 "  .amdhsa_system_sgpr_workgroup_id_y 1", "  .amdhsa_system_sgpr_workgroup_id_z 1",
@@ -1027,9 +1121,9 @@ class Gen:
                 "  .amdhsa_ieee_mode 1", ".end_amdhsa_kernel", "",
                 ".amdgpu_metadata", "---", "amdhsa.version:", "  - 1", "  - 2", "amdhsa.kernels:",
                 "  - .name: %s" % name, "    .symbol: %s.kd" % name, "    .kernarg_segment_size: %d" % kargs,
-                "    .kernarg_segment_align: 8", "    .group_segment_fixed_size: %d" % (P.ring * 256 * P.VPL), "    .private_segment_fixed_size: 0",
+                "    .kernarg_segment_align: 8", "    .group_segment_fixed_size: %d" % lds_bytes, "    .private_segment_fixed_size: 0",
                 "    .wavefront_size: 64", "    .sgpr_count: %d" % (NSGPR + 6), "    .vgpr_count: %d" % P.nvgpr_alloc,
-                "    .agpr_count: 0", "    .max_flat_workgroup_size: 64", "    .args:"]
+                "    .agpr_count: 0", "    .max_flat_workgroup_size: %d" % wg, "    .args:"]
         off = 0
         while off < kargs:
             out += ["      - .offset: %d" % off, "        .size: 8", "        .value_kind: by_value"]
@@ -1080,10 +1174,11 @@ def main():
     ap.add_argument("--ntload", action="store_true", help="non-temporal loads for region rows of unit-region pixels")
     ap.add_argument("--early", action="store_true", help="experimental: the program's first op dispatched from a scalar load")
     ap.add_argument("--pipe", type=int, default=0, help="the window is a program-managed ring of --w slots; the widest unit")
+    ap.add_argument("--tile", type=int, default=0, help="waves per workgroup that share their region rows through LDS (0: none)")
     ap.add_argument("-o", default=None)
     ap.add_argument("--header", default=None)
     a = ap.parse_args()
-    P = Params(vpl=a.vpl, K=a.k, W=a.w, NB=a.nb, PF=a.pf, wta=a.wta, order=a.order, minvgpr=a.minvgpr, skip=a.skip, ring=a.ring, persist=a.persist, pipe=a.pipe, ntload=a.ntload, early=a.early)
+    P = Params(vpl=a.vpl, K=a.k, W=a.w, NB=a.nb, PF=a.pf, wta=a.wta, order=a.order, minvgpr=a.minvgpr, skip=a.skip, ring=a.ring, persist=a.persist, pipe=a.pipe, ntload=a.ntload, early=a.early, tile=a.tile)
     g = Gen(P).build()
     if a.o:
         open(a.o, "w").write(g.render())

@@ -8,6 +8,11 @@ without a GPU.  It models what the kernel relies on and nothing more:
   * raw buffer loads / stores with the range check on voffset + soffset + inst_offset against num_records
   * outstanding vector loads: a VGPR with a load in flight may not be read before an s_waitcnt vmcnt(k) retires it
   * `pseudo_div` markers (one correctly rounded float32 division instead of the v_div_scale ... v_div_fixup sequence)
+  * (round 6, the tile kernels) workgroups of several waves: `run_workgroup` steps the waves from barrier to barrier;
+    LDS shared by them; buffer_load ... lds (bytes land at M0 + offset + lane * size); ds_read_b32 .. b128 with their
+    own in-flight tracking (a VGPR may not be read before s_waitcnt lgkmcnt(0)); and the hand-over discipline the kernel
+    must keep: LDS bytes a wave has requested may be read only after THAT wave's s_waitcnt vmcnt has retired the
+    request and - by another wave - after a barrier behind that wait
 """
 import re
 import struct
@@ -53,6 +58,41 @@ class Memory:
         return self.read(addr, count * np.dtype(dtype).itemsize).view(dtype).copy()
 
 
+class Lds:
+    """LDS of one workgroup + the state of every 16-byte granule: 0 ready for every wave, (1, w) requested by wave w and
+    still in flight, (2, w) landed for wave w (its s_waitcnt has retired the request) but not yet behind a barrier."""
+
+    def __init__(self, nbytes):
+        self.data = np.zeros(nbytes, np.uint8)
+        self.state = {}
+
+    def dma_write(self, wave_id, addr, data):
+        if addr < 0 or addr + len(data) > self.data.size:
+            raise SimError("LDS write of %d bytes at %d outside the %d allocated" % (len(data), addr, self.data.size))
+        self.data[addr:addr + len(data)] = data
+        for g in range(addr // 16, (addr + len(data) + 15) // 16):
+            self.state[g] = (1, wave_id)
+
+    def landed(self, wave_id, granules):
+        for g in granules:
+            if self.state.get(g) == (1, wave_id):
+                self.state[g] = (2, wave_id)
+
+    def barrier(self):
+        for g in [g for g, st in self.state.items() if st[0] == 2]:
+            del self.state[g]
+
+    def read(self, wave_id, addr, n):
+        if addr < 0 or addr + n > self.data.size:
+            raise SimError("LDS read of %d bytes at %d outside the %d allocated" % (n, addr, self.data.size))
+        for g in range(addr // 16, (addr + n + 15) // 16):
+            st = self.state.get(g)
+            if st is not None and not (st[0] == 2 and st[1] == wave_id):
+                raise SimError("LDS bytes at %d read by wave %d while wave %d's request is %s" % (
+                    g * 16, wave_id, st[1], "in flight" if st[0] == 1 else "not behind a barrier"))
+        return self.data[addr:addr + n]
+
+
 _RE_S = re.compile(r"^s(\d+)$")
 _RE_SR = re.compile(r"^s\[(\d+):(\d+)\]$")
 _RE_V = re.compile(r"^(-?)v(\d+)$")
@@ -64,11 +104,13 @@ def f2u(x):
 
 
 class Wave:
-    def __init__(self, gen, mem, code_addr=0x7e00fffff000):
+    def __init__(self, gen, mem, code_addr=0x7e00fffff000, lds=None, wave_id=0):
         self.ins = [i for i in gen.ins]
         self.P = gen.P
         self.mem = mem
         self.code_addr = code_addr
+        self.lds = lds
+        self.wave_id = wave_id
         # byte offset -> instruction index; label -> index
         self.by_off, self.labels, off = {}, {}, 0
         for n, i in enumerate(self.ins):
@@ -95,6 +137,8 @@ class Wave:
         self.idx_en = False
         self.pending = []            # outstanding vector loads, oldest first: sets of VGPR numbers
         self.pending_regs = {}
+        self.pending_lds = []        # ... and, beside each of them, the LDS granules a buffer_load ... lds is filling
+        self.lgkm_regs = set()       # VGPRs with a ds_read in flight
         self.stats = dict(ins=0, valu=0, salu=0, vmem=0, smem=0, setpc=0)
 
     # ---- operands ----------------------------------------------------------------------------------------------------
@@ -157,6 +201,8 @@ class Wave:
     def _check_ready(self, n):
         if n in self.pending_regs:
             raise SimError("v%d read while its load is in flight (missing s_waitcnt)" % n)
+        if n in self.lgkm_regs:
+            raise SimError("v%d read while its ds_read is in flight (missing s_waitcnt lgkmcnt)" % n)
 
     def rv(self, x, which):
         """Vector source as uint32[64] (VGPR, SGPR broadcast or constant)."""
@@ -197,12 +243,31 @@ class Wave:
 
     def _buf(self, i, store):
         nreg = {"dword": 1, "dwordx2": 2, "dwordx3": 3, "dwordx4": 4}[i.op.split("_")[-1]]
-        regs = self.vrange(i.args[0])
-        assert len(regs) == nreg
-        voff = self.rv(i.args[1], 0).astype(np.int64) if i.mods.get("offen") else np.zeros(64, np.int64)
-        base, nrec = self._rsrc(i.args[2])
-        soff = self.rs(i.args[3])
         imm = int(i.mods.get("offset", 0) or 0)
+        if not i.mods.get("lds"):
+            regs = self.vrange(i.args[0])
+            assert len(regs) == nreg
+            voff = self.rv(i.args[1], 0).astype(np.int64) if i.mods.get("offen") else np.zeros(64, np.int64)
+            base, nrec = self._rsrc(i.args[2])
+            soff = self.rs(i.args[3])
+        if i.mods.get("lds"):
+            # buffer_load ... lds: args = (voffset, rsrc, soffset); every lane's bytes go to LDS at M0 + imm + lane * size
+            nb = 4 * nreg
+            voff = self.rv(i.args[0], 0).astype(np.int64) if i.mods.get("offen") else np.zeros(64, np.int64)
+            base, nrec = self._rsrc(i.args[1])
+            soff = self.rs(i.args[2])
+            if self.idx_en:
+                raise SimError("buffer_load ... lds while VGPR index mode owns M0")
+            row = np.zeros(64 * nb, np.uint8)
+            for lane in range(64):
+                off = int(voff[lane]) + soff + imm
+                if off + nb <= nrec:
+                    row[lane * nb:(lane + 1) * nb] = self.mem.read(base + off, nb)
+            a0 = (self.m0 & 0xffff) + 0
+            self.lds.dma_write(self.wave_id, a0, row)
+            self.pending.append(set())
+            self.pending_lds.append(list(range(a0 // 16, (a0 + 64 * nb + 15) // 16)))
+            return
         if store:
             for r in regs:
                 self._check_ready(r)
@@ -220,11 +285,15 @@ class Wave:
                 if r >= self.nvgpr:
                     raise SimError("load into v%d beyond the %d allocated" % (r, self.nvgpr))
             self.pending.append(set(regs))
+            self.pending_lds.append(None)
             for r in regs:
                 self.pending_regs[r] = self.pending_regs.get(r, 0) + 1
 
     def _retire(self, keep):
         while len(self.pending) > keep:
+            granules = self.pending_lds.pop(0)
+            if granules is not None:
+                self.lds.landed(self.wave_id, granules)
             for r in self.pending.pop(0):
                 self.pending_regs[r] -= 1
                 if self.pending_regs[r] == 0:
@@ -232,6 +301,18 @@ class Wave:
 
     # ---- run ------------------------------------------------------------------------------------------------------------
     def run(self, sregs, v0, nvgpr, max_ins=2000000, trace=None):
+        """One wave on its own (a barrier is passed at once)."""
+        g = self.run_gen(sregs, v0, nvgpr, max_ins, trace)
+        while True:
+            try:
+                next(g)
+                if self.lds is not None:
+                    self.lds.barrier()
+            except StopIteration as e:
+                return e.value
+
+    def run_gen(self, sregs, v0, nvgpr, max_ins=2000000, trace=None):
+        """Generator: yields at every s_barrier, returns the statistics at s_endpgm."""
         self.reset()
         self.nvgpr = nvgpr
         for k, val in sregs.items():
@@ -315,6 +396,10 @@ class Wave:
                 m = re.match(r"vmcnt\((\d+)\)", a[0])
                 if m:
                     self._retire(int(m.group(1)))
+                if re.match(r"lgkmcnt\(0\)", a[0]):
+                    self.lgkm_regs.clear()
+            elif op == "s_barrier":
+                yield "barrier"
             elif op == "s_nop":
                 pass
             elif op == "s_mov_b32":
@@ -439,5 +524,58 @@ class Wave:
                     n = self._vidx(int(m.group(2)), 0)
                     self._check_ready(n)
                     self.ws(a[0], int(self.v[n, self.rs(a[2]) & 63]))
+                elif op == "v_readfirstlane_b32":
+                    m = _RE_V.match(a[1])
+                    n = int(m.group(2))                      # (VOP1 operands are not indexed in SRC1 mode)
+                    self._check_ready(n)
+                    self.ws(a[0], int(self.v[n, 0]))
+                elif op == "v_and_b32":
+                    self.wv(a[0], self.rv(a[1], 0) & self.rv(a[2], 1))
+                elif op == "v_lshrrev_b32":
+                    self.wv(a[0], self.rv(a[2], 1) >> (self.rv(a[1], 0) & 31))
+                elif op in ("ds_read_b32", "ds_read_b64", "ds_read_b96", "ds_read_b128"):
+                    self.stats["valu"] -= 1
+                    nreg = {"b32": 1, "b64": 2, "b96": 3, "b128": 4}[op.split("_")[-1]]
+                    regs = self.vrange(a[0])
+                    assert len(regs) == nreg
+                    m = _RE_V.match(a[1])
+                    an = int(m.group(2))                     # (DS addresses are not indexed)
+                    self._check_ready(an)
+                    imm = int(i.mods.get("offset", 0) or 0)
+                    for lane in range(64):
+                        addr = int(self.v[an, lane]) + imm
+                        vals = self.lds.read(self.wave_id, addr, 4 * nreg).view(np.uint32)
+                        for c, r in enumerate(regs):
+                            if r >= self.nvgpr:
+                                raise SimError("ds_read into v%d beyond the %d allocated" % (r, self.nvgpr))
+                            self.v[r, lane] = vals[c]
+                    self.lgkm_regs.update(regs)
                 else:
                     raise SimError("instruction %s is not modelled" % op)
+
+
+def run_workgroup(gen, mem, nwaves, sregs, nvgpr, lds_bytes, code_addr=0x7e00fffff000, max_ins=2000000):
+    """One workgroup of `nwaves` waves (work-item ids 0 .. 64 nwaves - 1 in v0) sharing an LDS of lds_bytes: every wave
+    runs to its next s_barrier (or to its end), the barrier opens when every live wave has arrived.  A wave that ends
+    while others wait at a barrier is an error of the kernel (the hardware would release the barrier, but the kernels
+    here never do that).  Returns the summed statistics."""
+    lds = Lds(lds_bytes)
+    waves = [Wave(gen, mem, code_addr=code_addr, lds=lds, wave_id=w) for w in range(nwaves)]
+    gens = [w.run_gen(dict(sregs), np.arange(64, dtype=np.uint32) + 64 * k, nvgpr, max_ins) for k, w in enumerate(waves)]
+    live = list(range(nwaves))
+    tot = {}
+    while live:
+        arrived, ended = [], []
+        for k in live:
+            try:
+                next(gens[k])
+                arrived.append(k)
+            except StopIteration as e:
+                ended.append(k)
+                for key, val in e.value.items():
+                    tot[key] = tot.get(key, 0) + val
+        if arrived and ended:
+            raise SimError("waves %s ended while waves %s wait at a barrier" % (ended, arrived))
+        lds.barrier()
+        live = arrived
+    return tot

@@ -54,6 +54,101 @@ def unit_region(word):
     return (int(word) & 0xfffff) == 0
 
 
+def step_sets(K, G, ok, up, dn, nd, t):
+    """Anchor rows of every column that take part in sweep step t (pf:155: self, up 1.., then down 1..)."""
+    aset = np.zeros(G, int)
+    for k in range(K):
+        for j in range(G):
+            if not ok[k, j]:
+                continue
+            if t < nd:
+                on = K - 1 - k <= t <= K - 1 - k + up[k, j]
+            else:
+                on = k <= t - nd <= k + dn[k, j] - 1
+            if on:
+                aset[j] |= 1 << k
+    return aset
+
+
+def plan_row(sup0, W, yq, row0, x0, aset, L, units):
+    """The window units of ONE region row (yq) for the patch columns x0 .. x0 + G - 1 whose anchor-row sets are `aset`,
+    appended to `units` in execution order (see plan_units)."""
+    G, WW = L["G"], L.get("UW", L["W"])
+    MAXD, MAXA = L["MAXD"], L["MAXA"]
+    H = sup0.shape[0]
+    cols = [j for j in range(G) if aset[j]]
+    if not cols:
+        return
+    assert 0 <= yq < H
+    lr = {}
+    for j in cols:
+        _, _, l, r = arms_of(sup0[yq, x0 + j])
+        lr[j] = (min(l, R), min(r, R))
+    c = {j: j + R for j in cols}                                  # virtual slot of the column's own pixel
+
+    def unit(lo, hi, runs):
+        assert 1 <= hi - lo + 1 <= WW
+        p = (yq - row0) * W + (x0 - R + hi)
+        assert 0 <= p < 65536 or L.get("pipe") or L.get("tile"), "pixel index exceeds the op's 16-bit field"
+        # single-use row: every pixel of the window is a unit-region pixel (and lies in the patch's own columns)
+        single = R <= lo and hi < R + G and all(unit_region(sup0[yq, x0 - R + v]) for v in range(lo, hi + 1))
+        units.append((lo, hi, p, runs, single))
+
+    desc = lambda j, first, n: ("d", j, int(aset[j]), first, n)
+    asc = lambda j, first, n: ("a", j, int(aset[j]), first, n)
+    lo = min(c[j] - lr[j][0] for j in cols)
+    hi = max(c[j] + lr[j][1] for j in cols)
+    if hi - lo + 1 <= WW and max(lr[j][0] + 1 for j in cols) <= MAXD and max(lr[j][1] for j in cols) <= MAXA:
+        unit(lo, hi, [desc(j, c[j], lr[j][0] + 1) for j in cols] + [asc(j, c[j] + 1, lr[j][1]) for j in cols if lr[j][1]])
+        return
+    # wide row: windows over groups of columns, descending arms first
+    i = 0
+    while i < len(cols):
+        j = cols[i]
+        glo, ghi = c[j] - lr[j][0], c[j]
+        if ghi - glo + 1 > min(WW, MAXD):                          # one arm longer than the window: in pieces
+            first, left = c[j], lr[j][0] + 1
+            while left:
+                n = min(left, WW, MAXD)
+                unit(first - n + 1, first, [desc(j, first, n)])
+                first, left = first - n, left - n
+            i += 1
+            continue
+        grp = [j]
+        while i + len(grp) < len(cols):
+            j2 = cols[i + len(grp)]
+            nlo, nhi = min(glo, c[j2] - lr[j2][0]), max(ghi, c[j2])
+            if nhi - nlo + 1 > WW or lr[j2][0] + 1 > MAXD:
+                break
+            glo, ghi = nlo, nhi
+            grp.append(j2)
+        unit(glo, ghi, [desc(jj, c[jj], lr[jj][0] + 1) for jj in grp])
+        i += len(grp)
+    acols = [j for j in cols if lr[j][1]]
+    i = 0
+    while i < len(acols):
+        j = acols[i]
+        glo, ghi = c[j] + 1, c[j] + lr[j][1]
+        if ghi - glo + 1 > min(WW, MAXA):
+            first, left = c[j] + 1, lr[j][1]
+            while left:
+                n = min(left, WW, MAXA)
+                unit(first, first + n - 1, [asc(j, first, n)])
+                first, left = first + n, left - n
+            i += 1
+            continue
+        grp = [j]
+        while i + len(grp) < len(acols):
+            j2 = acols[i + len(grp)]
+            nlo, nhi = min(glo, c[j2] + 1), max(ghi, c[j2] + lr[j2][1])
+            if nhi - nlo + 1 > WW or lr[j2][1] > MAXA:
+                break
+            glo, ghi = nlo, nhi
+            grp.append(j2)
+        unit(glo, ghi, [asc(jj, c[jj] + 1, lr[jj][1]) for jj in grp])
+        i += len(grp)
+
+
 def plan_units(sup0, H, W, y0, x0, L, skip_unit=False):
     """The patch's work as a list of window units in execution order: (lo, hi, p_last, runs) - load virtual slots
     lo .. hi of one region row (p_last = pixel index of slot hi relative to the patch's first region row), then the arm
@@ -79,89 +174,8 @@ def plan_units(sup0, H, W, y0, x0, L, skip_unit=False):
     row0 = max(y0 - R, 0)
     for t in range(nd + na):
         yq = y0 + K - 1 - t if t < nd else y0 + 1 + (t - nd)
-        # anchors taking part in this step (pf:155: self, up 1.., then down 1..)
-        aset = np.zeros(G, int)
-        for k in range(K):
-            for j in range(G):
-                if not ok[k, j]:
-                    continue
-                if t < nd:
-                    on = K - 1 - k <= t <= K - 1 - k + up[k, j]
-                else:
-                    on = k <= t - nd <= k + dn[k, j] - 1
-                if on:
-                    aset[j] |= 1 << k
-        cols = [j for j in range(G) if aset[j]]
-        if not cols:
-            continue
-        assert 0 <= yq < H
-        lr = {}
-        for j in cols:
-            _, _, l, r = arms_of(sup0[yq, x0 + j])
-            lr[j] = (min(l, R), min(r, R))
-        c = {j: j + R for j in cols}                                  # virtual slot of the column's own pixel
-
-        def unit(lo, hi, runs):
-            assert 1 <= hi - lo + 1 <= WW
-            p = (yq - row0) * W + (x0 - R + hi)
-            assert 0 <= p < 65536 or L.get("pipe"), "pixel index exceeds the op's 16-bit field"
-            # single-use row: every pixel of the window is a unit-region pixel (and lies in the patch's own columns)
-            single = R <= lo and hi < R + G and all(unit_region(sup0[yq, x0 - R + v]) for v in range(lo, hi + 1))
-            units.append((lo, hi, p, runs, single))
-
-        desc = lambda j, first, n: ("d", j, int(aset[j]), first, n)
-        asc = lambda j, first, n: ("a", j, int(aset[j]), first, n)
-        lo = min(c[j] - lr[j][0] for j in cols)
-        hi = max(c[j] + lr[j][1] for j in cols)
-        if hi - lo + 1 <= WW and max(lr[j][0] + 1 for j in cols) <= MAXD and max(lr[j][1] for j in cols) <= MAXA:
-            unit(lo, hi, [desc(j, c[j], lr[j][0] + 1) for j in cols] + [asc(j, c[j] + 1, lr[j][1]) for j in cols if lr[j][1]])
-            continue
-        # wide row: windows over groups of columns, descending arms first
-        i = 0
-        while i < len(cols):
-            j = cols[i]
-            glo, ghi = c[j] - lr[j][0], c[j]
-            if ghi - glo + 1 > min(WW, MAXD):                          # one arm longer than the window: in pieces
-                first, left = c[j], lr[j][0] + 1
-                while left:
-                    n = min(left, WW, MAXD)
-                    unit(first - n + 1, first, [desc(j, first, n)])
-                    first, left = first - n, left - n
-                i += 1
-                continue
-            grp = [j]
-            while i + len(grp) < len(cols):
-                j2 = cols[i + len(grp)]
-                nlo, nhi = min(glo, c[j2] - lr[j2][0]), max(ghi, c[j2])
-                if nhi - nlo + 1 > WW or lr[j2][0] + 1 > MAXD:
-                    break
-                glo, ghi = nlo, nhi
-                grp.append(j2)
-            unit(glo, ghi, [desc(jj, c[jj], lr[jj][0] + 1) for jj in grp])
-            i += len(grp)
-        acols = [j for j in cols if lr[j][1]]
-        i = 0
-        while i < len(acols):
-            j = acols[i]
-            glo, ghi = c[j] + 1, c[j] + lr[j][1]
-            if ghi - glo + 1 > min(WW, MAXA):
-                first, left = c[j] + 1, lr[j][1]
-                while left:
-                    n = min(left, WW, MAXA)
-                    unit(first, first + n - 1, [asc(j, first, n)])
-                    first, left = first + n, left - n
-                i += 1
-                continue
-            grp = [j]
-            while i + len(grp) < len(acols):
-                j2 = acols[i + len(grp)]
-                nlo, nhi = min(glo, c[j2] + 1), max(ghi, c[j2] + lr[j2][1])
-                if nhi - nlo + 1 > WW or lr[j2][1] > MAXA:
-                    break
-                glo, ghi = nlo, nhi
-                grp.append(j2)
-            unit(glo, ghi, [asc(jj, c[jj] + 1, lr[jj][1]) for jj in grp])
-            i += len(grp)
+        aset = step_sets(K, G, ok, up, dn, nd, t)
+        plan_row(sup0, W, yq, row0, x0, aset, L, units)
     return units
 
 
@@ -308,6 +322,126 @@ def build_all(sup0, H, W, L, skip_unit=False):
             longest = max(longest, len(p))
             out[rg, cg, :len(p)] = p
     return out, dict(band_rows=br, band_groups=bg, ngroups=ngroups, stride=stride, longest=longest)
+
+
+def tile_shape(H, W, L):
+    """Launch geometry of the tile kernels (cbca_prog_gen.py, tile): row groups of the 8 bands, tiles per row, padded
+    column groups, words per program."""
+    K, G, NW = L["K"], L["G"], L["tile"]
+    br = band_rows_of(H, K)
+    ntx = -(-W // (G * NW))
+    return dict(band_rows=br, band_groups=br // K, ntx=ntx, ngroups=ntx * NW, stride=tile_stride_dwords(L))
+
+
+def tile_stride_dwords(L):
+    """Upper bound of a tile wave's program: a patch program's ops (prog_stride_dwords) + per sweep step the two words
+    of a STEP op and a pad word."""
+    K = L["K"]
+    n = prog_stride_dwords(L) + 3 * (2 * K + 2 * R - 1)
+    n += n // 63 + 1
+    return -(-n // 64) * 64
+
+
+def build_tile_programs(sup0, H, W, y0, tx, L, skip_unit=False):
+    """The programs of the NW = L["tile"] waves of one tile (rows y0 .., columns tx * NW * G ..): every sweep step of the
+    TILE (the schedule of patch_setup / plan_units over all NW x G columns) is a STEP op in every wave's program - the
+    union of the tile's horizontal arms in that region row goes to LDS slots 0 .. - followed by the wave's own window
+    units as LOADL (LDS slot of the window's first pixel) + the unchanged ADD ops."""
+    K, G, NW, WW, RS = L["K"], L["G"], L["tile"], L["W"], L["RS"]
+    MAXD, MAXA, BLK, M0 = L["MAXD"], L["MAXA"], L["BLK"], L["M0_SRC1"]
+    TW = NW * G
+    x0t = tx * TW
+    up, dn, ok = np.zeros((K, TW), int), np.zeros((K, TW), int), np.zeros((K, TW), bool)
+    lowest = highest = y0
+    for k in range(K):
+        y = y0 + k
+        for c in range(TW):
+            x = x0t + c
+            if x < W and y < H and not (skip_unit and unit_region(sup0[y, x])):
+                u, d, _, _ = arms_of(sup0[y, x])
+                u, d = min(u, y), min(d, H - 1 - y)
+                up[k, c], dn[k, c], ok[k, c] = u, d, True
+                lowest = min(lowest, y - u)
+                highest = max(highest, y + d if d > 0 else y0)
+    nd = y0 + K - 1 - lowest + 1
+    na = highest - y0
+    row0 = max(y0 - R, 0)
+    progs = [[] for _ in range(NW)]
+    nop = L["wait"][-1] | (M0 << 16)                      # s_waitcnt vmcnt(W): waits for nothing
+
+    def emit(w, op):
+        ops = progs[w]
+        if len(ops) % 64 == 63:
+            ops.append(L["refill"] | (M0 << 16))
+        ops.append(op & 0xffffffff)
+
+    stats = dict(steps=0, slots=0, units=0)
+    for t in range(nd + na):
+        yq = y0 + K - 1 - t if t < nd else y0 + 1 + (t - nd)
+        aset = step_sets(K, TW, ok, up, dn, nd, t)
+        cols = [c for c in range(TW) if aset[c]]
+        if not cols:
+            continue
+        lo_t, hi_t = 1 << 30, -1
+        for c in cols:
+            _, _, l, r = arms_of(sup0[yq, x0t + c])
+            lo_t, hi_t = min(lo_t, c + R - min(l, R)), max(hi_t, c + R + min(r, R))
+        nslots = hi_t - lo_t + 1
+        assert 1 <= nslots <= L["SLOTS"]
+        p = (yq - row0) * W + (x0t - R + lo_t)            # pixel index of LDS slot 0 relative to the first region row
+        assert p >= 0
+        stats["steps"] += 1
+        stats["slots"] += nslots
+        for w in range(NW):
+            if len(progs[w]) % 64 >= 62:                  # a STEP's two words stay in one 64-op chunk (63 = its REFILL)
+                emit(w, nop)
+                if len(progs[w]) % 64 == 63:
+                    emit(w, nop)
+            emit(w, L["step"] | (nslots << 16))
+            emit(w, p)
+            assert len(progs[w]) % 64 != 0 or True
+            units = []
+            plan_row(sup0, W, yq, row0, x0t + w * G, aset[w * G:(w + 1) * G], L, units)
+            for lo, hi, _, runs, _ in units:
+                n = hi - lo + 1
+                first = w * G + lo - lo_t                 # LDS slot of the window's first pixel
+                assert 0 <= first and first + n <= nslots
+                emit(w, L["loadl"][n] | (first << 16))
+                stats["units"] += 1
+                for d, j, aset_all, firstv, cnt in runs:
+                    sf = firstv - lo
+                    for a in decompose(aset_all, K):
+                        nk = bin(a).count("1")
+                        if d == "d":
+                            assert 1 <= cnt <= MAXD and 0 <= sf - cnt + 1 and sf < WW
+                            emit(w, (L["add"][(j, a, "d")] + (MAXD - cnt) * BLK * nk) | ((M0 | (RS * (sf - cnt + 1))) << 16))
+                        else:
+                            assert 1 <= cnt <= MAXA and 0 <= sf and sf + cnt - 1 < WW
+                            emit(w, (L["add"][(j, a, "a")] + (MAXA - cnt) * BLK * nk) | ((M0 | (RS * (sf + cnt - 1))) << 16))
+    for w in range(NW):
+        emit(w, L["end"] | (M0 << 16))
+    return [np.array(o, np.uint32) for o in progs], stats
+
+
+def build_all_tiles(sup0, H, W, L, skip_unit=False):
+    """[row groups of the 8 bands][padded column groups][stride] uint32: the layout the tile kernels index."""
+    K, G, NW = L["K"], L["G"], L["tile"]
+    m = tile_shape(H, W, L)
+    out = np.zeros((8 * m["band_groups"], m["ngroups"], m["stride"]), np.uint32)
+    longest, tot = 0, dict(steps=0, slots=0, units=0)
+    for rg in range(8 * m["band_groups"]):
+        y0 = rg * K
+        for tx in range(m["ntx"]):
+            if y0 >= H:
+                continue
+            progs, st = build_tile_programs(sup0, H, W, y0, tx, L, skip_unit)
+            for k in tot:
+                tot[k] += st[k]
+            for w, pw in enumerate(progs):
+                assert len(pw) <= m["stride"], (len(pw), m["stride"])
+                longest = max(longest, len(pw))
+                out[rg, tx * NW + w, :len(pw)] = pw
+    return out, dict(m, longest=longest, **tot)
 
 
 def decode_tables(L):

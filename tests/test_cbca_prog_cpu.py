@@ -165,6 +165,77 @@ def simulate(g, L, img, vol, code_addr=0x7e00fffff000, out_init=None):
     return out.transpose(2, 0, 1), tot
 
 
+def simulate_tile(g, L, img, vol, out_init=None):
+    """Every workgroup of one single-volume launch of a TILE kernel (cbca_prog_gen.py, tile = NW waves per workgroup that
+    share their region rows through LDS) in the simulator: NW waves stepped from barrier to barrier over one LDS."""
+    P = g.P
+    D, H, W = vol.shape
+    Dp = -(-D // 4) * 4 if P.VPL != 3 else -(-D // 3) * 3
+    sup0 = support_words(img)
+    L = dict(L, pix=4 * Dp)
+    progs, meta = ref.build_all_tiles(sup0, H, W, L, skip_unit=P.skip)
+    hwd = np.zeros((H, W, Dp), np.float32)
+    hwd[:, :, :D] = vol.transpose(1, 2, 0)
+    mem = asm_sim.Memory()
+    a_in = mem.alloc(hwd)
+    out0 = np.full((H, W, Dp), np.nan, np.float32)
+    if out_init is not None:
+        out0[:, :, :D] = out_init.transpose(1, 2, 0)
+    a_out = mem.alloc(out0)
+    a_prog = mem.alloc(progs)
+    a_sup = mem.alloc(np.concatenate([sup0.reshape(-1), np.zeros(64, np.uint32)]))
+    nchunks = -(-Dp // (64 * P.VPL))
+    karg = np.zeros(0x60 // 4, np.uint32)
+
+    def put64(i, v):
+        karg[i], karg[i + 1] = v & 0xffffffff, v >> 32
+    put64(0, a_in), put64(2, a_in), put64(4, a_out), put64(6, a_out), put64(8, a_prog), put64(10, a_prog)
+    put64(12, a_sup), put64(14, a_sup)
+    karg[16:24] = [Dp, H, W, nchunks, meta["band_rows"], meta["band_groups"], meta["stride"] * 4, meta["ngroups"]]
+    a_k = mem.alloc(karg)
+    tot = {}
+    for bx in range(8 * meta["band_groups"]):
+        for by in range(meta["ntx"]):
+            for bz in range(nchunks):
+                st = asm_sim.run_workgroup(g, mem, P.tile, {0: a_k & 0xffffffff, 1: a_k >> 32, 2: bx, 3: by, 4: bz}, P.nvgpr,
+                                           P.SLOTS * P.SB)
+                for k, v in st.items():
+                    tot[k] = tot.get(k, 0) + v
+    out = mem.get(a_out, np.float32, H * W * Dp).reshape(H, W, Dp)[:, :, :D]
+    return out.transpose(2, 0, 1), tot, meta
+
+
+@pytest.mark.parametrize("vpl,nw,H,W,D,seed,flat", [(4, 4, 12, 17, 8, 0, False), (4, 4, 9, 33, 4, 2, True), (4, 4, 24, 45, 6, 3, False),
+                                                     (4, 2, 14, 23, 5, 4, False), (2, 4, 11, 26, 6, 5, False),
+                                                     (4, 4, 7, 12, 300, 7, False), (4, 4, 30, 64, 4, 8, True)])
+def test_tile_kernel_reproduces_the_oracle_in_the_simulator(vpl, nw, H, W, D, seed, flat):
+    """The kernel whose region rows travel through LDS once per TILE of nw patches (a workgroup of nw waves in lock
+    step: STEP = barrier, each wave's share of the row by buffer_load ... lds, wait, barrier; LOADL = a patch's window
+    out of LDS; the unchanged ADD lines): the oracle's bits, with the simulator checking that no wave reads LDS bytes
+    whose request has not been retired by its issuer and published by a barrier."""
+    g = gen.Gen(gen.Params(vpl=vpl, K=4, W=20, tile=nw)).build()
+    L = g.layout()
+    img, vol = make_case(H, W, D, seed, flat)
+    got, st, meta = simulate_tile(g, L, img, vol)
+    assert_bits_strict(got, oracle_cbca(img, vol), "tile kernel in the simulator against the oracle")
+    assert meta["steps"] > 0 and meta["slots"] >= meta["steps"]
+
+
+def test_tile_skip_kernel_equals_the_oracle_in_the_simulator():
+    g = gen.Gen(gen.Params(vpl=4, K=4, W=20, tile=4, skip=True)).build()
+    L = g.layout()
+    img, vol0 = make_case(24, 45, 6, 3)
+    v1 = oracle_cbca(img, vol0)
+    v2 = oracle_cbca(img, v1)
+    v3 = oracle_cbca(img, v2)
+    unit = (support_words(img) & 0xfffff) == 0
+    assert unit.any() and not unit.all()
+    got, _, _ = simulate_tile(g, L, img, v2, out_init=v1)
+    assert_bits_strict(got, v3, "tile skip kernel against the oracle's third iteration")
+    untouched, _, _ = simulate_tile(g, L, img, v2)
+    assert np.isnan(untouched[:, unit]).all() and np.array_equal(untouched[:, ~unit], v3[:, ~unit])
+
+
 @pytest.mark.parametrize("vpl,w,nb,H,W,D,seed,flat", [(4, 12, 1, 12, 17, 8, 0, False), (4, 12, 1, 9, 33, 4, 2, True),
                                                        (3, 12, 1, 14, 23, 6, 4, False), (2, 12, 1, 11, 16, 6, 5, False),
                                                        (4, 8, 1, 13, 21, 5, 6, True), (4, 12, 1, 7, 12, 300, 7, False),
