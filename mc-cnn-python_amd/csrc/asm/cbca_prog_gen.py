@@ -1177,7 +1177,16 @@ def main():
     ap.add_argument("--tile", type=int, default=0, help="waves per workgroup that share their region rows through LDS (0: none)")
     ap.add_argument("-o", default=None)
     ap.add_argument("--header", default=None)
+    ap.add_argument("--experimental", action="store_true",
+                    help="required for every variant that was measured and NOT adopted (--nb 2, --pf, --ring, --persist, "
+                         "--pipe, --ntload, --early, --tile, --minvgpr): the library's build (Makefile) never passes it, so a "
+                         "shipped code object cannot pick one up by accident")
     a = ap.parse_args()
+    experimental = [n for n, on in (("--nb", a.nb != 1), ("--pf", a.pf), ("--ring", a.ring), ("--persist", a.persist),
+                                    ("--pipe", a.pipe), ("--ntload", a.ntload), ("--early", a.early), ("--tile", a.tile),
+                                    ("--minvgpr", a.minvgpr), ("--order", a.order)) if on]
+    if experimental and not a.experimental:
+        ap.error("%s: measured and not adopted - pass --experimental to generate it anyway" % ", ".join(experimental))
     P = Params(vpl=a.vpl, K=a.k, W=a.w, NB=a.nb, PF=a.pf, wta=a.wta, order=a.order, minvgpr=a.minvgpr, skip=a.skip, ring=a.ring, persist=a.persist, pipe=a.pipe, ntload=a.ntload, early=a.early, tile=a.tile)
     g = Gen(P).build()
     if a.o:

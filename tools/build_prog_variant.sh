@@ -9,9 +9,9 @@ NAME=$1; GEN=$2; DEFS=$3
 LLVM=/opt/rocm/lib/llvm/bin
 A=build/variants/$NAME/asm; mkdir -p $A
 for v in 2 3 4; do
-  python3 csrc/asm/cbca_prog_gen.py --vpl $v $GEN -o $A/cbca_prog_v$v.s --header $A/cbca_prog_layout_v$v.h
-  python3 csrc/asm/cbca_prog_gen.py --vpl $v $GEN --wta -o $A/cbca_prog_v${v}w.s
-  python3 csrc/asm/cbca_prog_gen.py --vpl $v $GEN --skip -o $A/cbca_prog_v${v}s.s
+  python3 csrc/asm/cbca_prog_gen.py --experimental --vpl $v $GEN -o $A/cbca_prog_v$v.s --header $A/cbca_prog_layout_v$v.h
+  python3 csrc/asm/cbca_prog_gen.py --experimental --vpl $v $GEN --wta -o $A/cbca_prog_v${v}w.s
+  python3 csrc/asm/cbca_prog_gen.py --experimental --vpl $v $GEN --skip -o $A/cbca_prog_v${v}s.s
   for s in v$v v${v}w v${v}s; do
     $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c $A/cbca_prog_$s.s -o $A/cbca_prog_$s.o
     $LLVM/ld.lld -shared $A/cbca_prog_$s.o -o $A/cbca_prog_$s.hsaco
