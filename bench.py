@@ -540,8 +540,7 @@ def main():
             fuse = name == "aggregation_2" and D <= sd.cbca_hwd_wta_max_d()
             n_skip = 0
             if unit_fraction is not None and matcher.skip_unit_regions:
-                n_skip = sum(1 for it in range(n_it)
-                             if it >= 1 and not (fuse and it == n_it - 1) and not (n_it % 2 == 0 and it == n_it - 1))
+                n_skip = sd.skip_schedule(n_it, fuse, True, matcher.refresh_first).count("skip")
             proc = (n_it - n_skip) * 4 * vol_bytes
             if n_skip:
                 proc += n_skip * 2 * vol_bytes * ((1.0 - unit[0]) + (1.0 - unit[1]))

@@ -45,7 +45,7 @@ extern "C" {
 
 typedef void *mccnn_stream_t; /* hipStream_t */
 
-#define MCCNN_ABI_VERSION 6 /* 2: window-mask plane, *_hwd entry points; 3: saturation flags; 4: program-driven CBCA; 5: skip programs; 6: one-volume launches */
+#define MCCNN_ABI_VERSION 7 /* 2: window-mask plane, *_hwd entry points; 3: saturation flags; 4: program-driven CBCA; 5: skip programs; 6: one-volume launches; 7: refresh launches */
 
 #define MCCNN_E_INVALID (-1)     /* bad argument (null pointer, non-positive size, unsupported shape) */
 #define MCCNN_E_UNSUPPORTED (-2) /* shape outside what the kernels were built for (e.g. D > 512 for SGM) */
@@ -230,6 +230,21 @@ int mccnn_cbca_iter_prog(const float *in, float *out, const mccnn_support_t *sup
                          int L, mccnn_stream_t stream);
 int mccnn_cbca_iter_prog_skip(const float *in, float *out, const mccnn_support_t *support, const void *prog, int D, int H,
                               int W, int L, mccnn_stream_t stream);
+
+/* The FIRST iteration of an aggregation whose later iterations run the skip programs (round 6): exactly
+ * mccnn_cbca_iter_prog(_pair) - the full programs, every pixel of `out` written - and, besides, the value v1 = (0 + v0) / 1
+ * of every unit-region pixel is written back into `in` (pf:156-161 with aver_num = 1: `in` is NOT const here).  After
+ * it both buffers of the ping-pong pair hold v1 at those pixels, so EVERY later iteration may be a _skip launch,
+ * whichever buffer the last one writes: without it `in` keeps v0, which differs from v1 where v0 is -0.0, and an
+ * aggregation with an even number of iterations (match.py's first: 2) had to end with a full launch.  Waves that read
+ * such a pixel as a neighbour while it is being rewritten see v0 or v1 - as an operand the two give the same bits (see
+ * above), so the race cannot be observed.  Same programs, same refusals as mccnn_cbca_iter_prog(_pair). */
+int mccnn_cbca_iter_prog_refresh(float *in, float *out, const mccnn_support_t *support, const void *prog, int D, int H, int W,
+                                 int L, mccnn_stream_t stream);
+int mccnn_cbca_iter_prog_pair_refresh(float *in_left, float *out_left, const mccnn_support_t *support_left,
+                                      const void *prog_left, float *in_right, float *out_right,
+                                      const mccnn_support_t *support_right, const void *prog_right, int D, int H, int W,
+                                      int L, mccnn_stream_t stream);
 
 /* ---- layout changes between DHW and HWD ------------------------------------------------------------------- */
 int mccnn_hwd_pitch(int D); /* Dp: D rounded up to a multiple of 4 (16-byte rows) */

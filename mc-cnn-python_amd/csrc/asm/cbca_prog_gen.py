@@ -125,8 +125,17 @@ def ins_size(i):
 
 class Params:
     def __init__(self, vpl=4, K=2, G=5, W=12, NB=1, PF=0, wta=False, debug=0, order=0, minvgpr=0, skip=False, ring=0, persist=False,
-                 pipe=0, ntload=False, early=False, tile=0):
+                 pipe=0, ntload=False, early=False, tile=0, refresh=False):
         assert K in (1, 2, 4, 8), "anchor sets are aligned power-of-two groups of anchor rows"
+        # refresh (round 6): the kernel of an aggregation's FIRST iteration when later ones run the skip programs.  It is
+        # the full kernel, and it also stores the quotient of every anchor whose support region is the pixel itself -
+        # v1 = (0 + v0) / 1 - back into the INPUT buffer.  After it both buffers of the ping-pong pair hold v1 at those
+        # pixels, so EVERY later iteration may leave them alone, whichever buffer the last one writes (without it the
+        # input buffer keeps v0, which differs from v1 where v0 is -0.0, and an aggregation with an even number of
+        # iterations had to end with a full launch).  The race with waves that read such a pixel as a neighbour is
+        # benign: as an operand of a sum that began as 0 + x, v0 and v1 give the same bits.
+        self.refresh = refresh
+        assert not (refresh and (skip or wta)), "refresh is a variant of the plain full kernel"
         # tile (round 6): a workgroup of `tile` waves owns `tile` horizontally adjacent patches and sweeps their region rows
         # in lock step: a STEP op (every wave of the tile has the same ones at the same places) brings the union of the
         # tile's horizontal arms in one region row into LDS ONCE - every wave requests its share with buffer_load ... lds,
@@ -215,7 +224,8 @@ class Params:
     def name(self):
         if self.tile:
             return "mccnn_cbca_tile%d_v%d%s" % (self.tile, self.VPL, "_wta" if self.wta else "_skip" if self.skip else "")
-        return "mccnn_cbca_prog_v%d%s%s" % (self.VPL, "p" if self.pipe else "", "_wta" if self.wta else "_skip" if self.skip else "")
+        return "mccnn_cbca_prog_v%d%s%s" % (self.VPL, "p" if self.pipe else "",
+                                            "_wta" if self.wta else "_skip" if self.skip else "_refresh" if self.refresh else "")
 
 
 # ---- scalar register map ------------------------------------------------------------------------------------------
@@ -250,6 +260,7 @@ S = dict(
     rs_pn=84,          # s[84:87] (persist): descriptor of the next patch's program
     pfa=100,           # s[100:101]
     wave=90, st_n=91, st_lds=92, st_s=93, st_str=94,      # (tile) wave of the workgroup; STEP's loop state
+    rs_ref=84,         # s[84:87] (refresh): descriptor over the anchors' row of the INPUT buffer
 )
 NSGPR = 102
 
@@ -915,6 +926,12 @@ class Gen:
             e("s_add_u32", s("rs_out"), s("outp"), s("t1"))
             e("s_addc_u32", sreg(S["rs_out"] + 1), sreg(S["outp"] + 1), s("t2"))
             e("s_and_b32", sreg(S["rs_out"] + 1), sreg(S["rs_out"] + 1), 0xffff)
+            if P.refresh:      # the same window over the input buffer
+                e("s_add_u32", s("rs_ref"), s("inp"), s("t1"))
+                e("s_addc_u32", sreg(S["rs_ref"] + 1), sreg(S["inp"] + 1), s("t2"))
+                e("s_and_b32", sreg(S["rs_ref"] + 1), sreg(S["rs_ref"] + 1), 0xffff)
+                e("s_mov_b32", sreg(S["rs_ref"] + 2), sreg(S["rs_out"] + 2))
+                e("s_mov_b32", sreg(S["rs_ref"] + 3), 0x00020000)
             e("s_mov_b32", s("so"), 0)
             for j in range(G):
                 pol = {0: dict(nt=True), 4: {}, 8: dict(sc1=True), 12: dict(sc0=True, sc1=True), 16: dict(sc1=True, nt=True),
@@ -924,6 +941,12 @@ class Gen:
                     e("s_cbranch_scc0", "nostore_%d_%d" % (k, j))
                 self.vstore(P.acc(k, j), P.v_voff, S["rs_out"], s("so"), **pol)
                 e("s_nop", 0, comment="gfx950 store-data hazard (common.h)")
+                if P.refresh:       # a unit region: its value v1 also replaces v0 in the input buffer
+                    e("s_and_b32", s("t0"), sreg(S["cnt"] + k * G + j), 0xfffff)
+                    e("s_cbranch_scc1", "norefresh_%d_%d" % (k, j))
+                    self.vstore(P.acc(k, j), P.v_voff, S["rs_ref"], s("so"))
+                    e("s_nop", 0, comment="gfx950 store-data hazard (common.h)")
+                    self.label("norefresh_%d_%d" % (k, j))
                 if P.skip:
                     self.label("nostore_%d_%d" % (k, j))
                 if j + 1 < G:
@@ -1103,7 +1126,7 @@ class Gen:
             else:
                 line = i.render()
                 # local labels: branch targets and the code_base difference
-                line = re.sub(r"\b(code_base|after_getpc|done|pf_done|pf_loop\d+|load_b\d+_blk\d+|loadblk_\d+|loadnt_blk\d+|load_done|loadf_blk\d+|h_end|h_load1|h_loadf1|first_is_end|nodiv_\d+_\d+|nostore_\d+_\d+|pf_blk\d+|cp_blk\d+|loadl_blk\d+|step_loop|step_done|p_div|p_divd|p_z|p_patch|p_nextz|e_nofetch)\b", lambda m: ".L%s_%s" % (name, m.group(1)), line)
+                line = re.sub(r"\b(code_base|after_getpc|done|pf_done|pf_loop\d+|load_b\d+_blk\d+|loadblk_\d+|loadnt_blk\d+|load_done|loadf_blk\d+|h_end|h_load1|h_loadf1|first_is_end|nodiv_\d+_\d+|nostore_\d+_\d+|norefresh_\d+_\d+|pf_blk\d+|cp_blk\d+|loadl_blk\d+|step_loop|step_done|p_div|p_divd|p_z|p_patch|p_nextz|e_nofetch)\b", lambda m: ".L%s_%s" % (name, m.group(1)), line)
                 out.append(line)
         kargs = 0x80 if (P.wta or P.persist) else 0x60
         lds_bytes = P.SLOTS * P.SB if P.tile else P.ring * 256 * P.VPL
@@ -1170,6 +1193,8 @@ def main():
     ap.add_argument("--persist", action="store_true", help="experimental (with --ring): persistent waves")
     ap.add_argument("--ring", type=int, default=0, help="experimental: window rows through an LDS ring of this many slots")
     ap.add_argument("--skip", action="store_true", help="the kernel of the skip programs (unit regions neither divided nor stored)")
+    ap.add_argument("--refresh", action="store_true",
+                    help="the full kernel that also writes unit-region pixels back into its input buffer (first iteration)")
     ap.add_argument("--minvgpr", type=int, default=0, help="experiments: allocate at least this many VGPRs (occupancy)")
     ap.add_argument("--ntload", action="store_true", help="non-temporal loads for region rows of unit-region pixels")
     ap.add_argument("--early", action="store_true", help="experimental: the program's first op dispatched from a scalar load")
@@ -1187,7 +1212,7 @@ def main():
                                     ("--minvgpr", a.minvgpr), ("--order", a.order)) if on]
     if experimental and not a.experimental:
         ap.error("%s: measured and not adopted - pass --experimental to generate it anyway" % ", ".join(experimental))
-    P = Params(vpl=a.vpl, K=a.k, W=a.w, NB=a.nb, PF=a.pf, wta=a.wta, order=a.order, minvgpr=a.minvgpr, skip=a.skip, ring=a.ring, persist=a.persist, pipe=a.pipe, ntload=a.ntload, early=a.early, tile=a.tile)
+    P = Params(vpl=a.vpl, K=a.k, W=a.w, NB=a.nb, PF=a.pf, wta=a.wta, order=a.order, minvgpr=a.minvgpr, skip=a.skip, ring=a.ring, persist=a.persist, pipe=a.pipe, ntload=a.ntload, early=a.early, tile=a.tile, refresh=a.refresh)
     g = Gen(P).build()
     if a.o:
         open(a.o, "w").write(g.render())

@@ -53,13 +53,24 @@ alignas(4096) static const unsigned char kCodeV3s[] = {
 alignas(4096) static const unsigned char kCodeV4s[] = {
 #include "cbca_prog_v4s.inc"
 };
-// [kernel: 0 plain, 1 with WTA, 2 skip][disparities per lane - 2]
-enum { kPlain = 0, kWta = 1, kSkip = 2 };
-static const unsigned char *const kCode[3][3] = {{kCodeV2, kCodeV3, kCodeV4}, {kCodeV2w, kCodeV3w, kCodeV4w},
-                                                 {kCodeV2s, kCodeV3s, kCodeV4s}};
-static const char *const kName[3][3] = {{"mccnn_cbca_prog_v2", "mccnn_cbca_prog_v3", "mccnn_cbca_prog_v4"},
+alignas(4096) static const unsigned char kCodeV2r[] = {
+#include "cbca_prog_v2r.inc"
+};
+alignas(4096) static const unsigned char kCodeV3r[] = {
+#include "cbca_prog_v3r.inc"
+};
+alignas(4096) static const unsigned char kCodeV4r[] = {
+#include "cbca_prog_v4r.inc"
+};
+// [kernel: 0 plain, 1 with WTA, 2 skip, 3 refresh][disparities per lane - 2]
+enum { kPlain = 0, kWta = 1, kSkip = 2, kRefresh = 3 };
+static const unsigned char *const kCode[4][3] = {{kCodeV2, kCodeV3, kCodeV4}, {kCodeV2w, kCodeV3w, kCodeV4w},
+                                                 {kCodeV2s, kCodeV3s, kCodeV4s}, {kCodeV2r, kCodeV3r, kCodeV4r}};
+static const char *const kName[4][3] = {{"mccnn_cbca_prog_v2", "mccnn_cbca_prog_v3", "mccnn_cbca_prog_v4"},
                                         {"mccnn_cbca_prog_v2_wta", "mccnn_cbca_prog_v3_wta", "mccnn_cbca_prog_v4_wta"},
-                                        {"mccnn_cbca_prog_v2_skip", "mccnn_cbca_prog_v3_skip", "mccnn_cbca_prog_v4_skip"}};
+                                        {"mccnn_cbca_prog_v2_skip", "mccnn_cbca_prog_v3_skip", "mccnn_cbca_prog_v4_skip"},
+                                        {"mccnn_cbca_prog_v2_refresh", "mccnn_cbca_prog_v3_refresh",
+                                         "mccnn_cbca_prog_v4_refresh"}};
 
 // disparities per lane: 2 up to 128, 3 where that fills the lanes exactly (padded D a multiple of 3 up to 192), else 4
 // with 256-disparity chunks - the same rule as cbca_hwd.hip
@@ -75,7 +86,7 @@ struct Loaded {
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
 };
-static Loaded g_loaded[64][3][3];
+static Loaded g_loaded[64][4][3];
 static std::mutex g_mu;
 
 static int kernel_for(int vpl, int which, hipFunction_t *fn)
@@ -372,7 +383,8 @@ extern "C" int mccnn_cbca_prog_build_skip_pair(const mccnn_support_t *support_le
 static int prog_iter(const char *who, const float *in_left, float *out_left, const mccnn_support_t *support_left,
                      const void *prog_left, const float *in_right, float *out_right, const mccnn_support_t *support_right,
                      const void *prog_right, int D, int H, int W, int L, float *disp_left, float *disp_right,
-                     int store_right, bool wta, bool skip_unit, mccnn_stream_t stream, bool single = false)
+                     int store_right, bool wta, bool skip_unit, mccnn_stream_t stream, bool single = false,
+                     bool refresh = false)
 {
     using namespace mccnn;
     if (single) {       // one volume per launch: the launch has no second job, its slots repeat the first one's
@@ -403,7 +415,7 @@ static int prog_iter(const char *who, const float *in_left, float *out_left, con
     rc = prog::check_built(prog_right, support_right, D, H, W, skip_unit ? 1 : 0);
     if (rc) return rc;
     hipFunction_t fn;
-    rc = prog::kernel_for(s.vpl, wta ? prog::kWta : skip_unit ? prog::kSkip : prog::kPlain, &fn);
+    rc = prog::kernel_for(s.vpl, wta ? prog::kWta : skip_unit ? prog::kSkip : refresh ? prog::kRefresh : prog::kPlain, &fn);
     if (rc) return rc;
     if (skip_unit) {      // the second program set of both buffers
         prog_left = static_cast<const char *>(prog_left) + prog::set_bytes(s);
@@ -468,4 +480,22 @@ extern "C" int mccnn_cbca_iter_prog_pair_wta(const float *in_left, float *out_le
 {
     return prog_iter("mccnn_cbca_iter_prog_pair_wta", in_left, out_left, support_left, prog_left, in_right, out_right,
                      support_right, prog_right, D, H, W, L, disparity_left, disparity_right, store_right, true, false, stream);
+}
+
+// The first iteration of an aggregation whose later iterations run the skip programs (round 6): the full kernel, which
+// also writes the value of every unit-region pixel - v1 = (0 + v0) / 1 - back into `in`.
+extern "C" int mccnn_cbca_iter_prog_refresh(float *in, float *out, const mccnn_support_t *support, const void *prog, int D,
+                                            int H, int W, int L, mccnn_stream_t stream)
+{
+    return prog_iter("mccnn_cbca_iter_prog_refresh", in, out, support, prog, nullptr, nullptr, nullptr, nullptr, D, H, W, L,
+                     nullptr, nullptr, 1, false, false, stream, true, true);
+}
+
+extern "C" int mccnn_cbca_iter_prog_pair_refresh(float *in_left, float *out_left, const mccnn_support_t *support_left,
+                                                 const void *prog_left, float *in_right, float *out_right,
+                                                 const mccnn_support_t *support_right, const void *prog_right, int D, int H,
+                                                 int W, int L, mccnn_stream_t stream)
+{
+    return prog_iter("mccnn_cbca_iter_prog_pair_refresh", in_left, out_left, support_left, prog_left, in_right, out_right,
+                     support_right, prog_right, D, H, W, L, nullptr, nullptr, 1, false, false, stream, false, true);
 }

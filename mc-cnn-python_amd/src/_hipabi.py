@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MCCNN_HIP_LIB selects another build of the same library (kernel A/B measurements); there is still no CPU path.
 LIB_PATH = os.environ.get("MCCNN_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libmccnn_hip.so")
 
-MCCNN_ABI_VERSION = 6      # include/mccnn.h; load() refuses a library built from another header
+MCCNN_ABI_VERSION = 7      # include/mccnn.h; load() refuses a library built from another header
 MCCNN_CV_EXACT = 0
 MCCNN_CV_MFMA = 1
 MCCNN_CBCA_SEPARABLE = 0
@@ -52,6 +52,8 @@ SIGNATURES = {
     "mccnn_cbca_iter_prog_pair_skip": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mccnn_cbca_iter_prog": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mccnn_cbca_iter_prog_skip": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mccnn_cbca_iter_prog_refresh": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mccnn_cbca_iter_prog_pair_refresh": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mccnn_cbca_iter_prog_pair_wta": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "mccnn_wta_hwd": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mccnn_subpixel_hwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -133,7 +133,7 @@ def cost_volume_aggregation(left_image, right_image, left_cost_volume, right_cos
         progs = sd.cbca_prog_buffers(D, H, W, vl.device) if tuple(vr.shape) == (D, H, W) else None
         if progs is not None:
             sd.cbca_prog_build_pair(supports[0], supports[1], D, int(distance_threshold), progs,
-                                    "both" if int(max_average_time) > 2 else "full")
+                                    "both" if int(max_average_time) >= 2 else "full")
             hl, hr = sd.dhw_to_hwd(vl), sd.dhw_to_hwd(vr)       # copies: the caller's arrays stay as they are
             (rl, _), (rr, _) = sd.cbca_prog_pair(hl, torch.empty_like(hl), supports[0], hr, torch.empty_like(hr),
                                                  supports[1], progs, D, int(max_average_time), int(distance_threshold),

@@ -392,8 +392,32 @@ def right_stream(device):
     return _RIGHT_STREAMS[key]
 
 
+def skip_schedule(n, fused_last, skip_unit_regions=True, refresh_first=True):
+    """Which kernel every iteration of an n-iteration aggregation runs: a list of "full", "refresh" (the full kernel that
+    also writes unit-region pixels back into its input, mccnn_cbca_iter_prog_refresh), "skip" and "wta" (the full kernel
+    fused with a7; fused_last).  cbca_prog_pair's docstring has the argument."""
+    n = int(n)
+    kinds = []
+    for it in range(n):
+        if fused_last and it == n - 1:
+            kinds.append("wta")
+        elif not skip_unit_regions or it == 0:
+            kinds.append("full")
+        elif refresh_first or not (n % 2 == 0 and it == n - 1):
+            kinds.append("skip")
+        else:
+            kinds.append("full")
+    # The first iteration's input buffer X keeps v0 at unit-region pixels.  As operands v0 and v1 are interchangeable, so
+    # X matters only as the FINAL buffer: n even, and then only if the last iteration is a skip launch (a full / WTA
+    # launch rewrites every pixel).  Only then does the first iteration have to refresh X.
+    if n >= 2 and n % 2 == 0 and kinds[-1] == "skip":
+        kinds[0] = "refresh"
+    return kinds
+
+
 def cbca_prog_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, progs, D, iterations, distance_threshold, timer=None,
-                   wta_out=None, store_right=True, skip_unit_regions=True, skip_ready=None, right_stream=None):
+                   wta_out=None, store_right=True, skip_unit_regions=True, skip_ready=None, right_stream=None,
+                   refresh_first=True):
     """cbca_hwd_pair's result (bit for bit) through the program-driven assembly kernel (mccnn_cbca_iter_prog_pair);
     `progs` from cbca_prog_build_pair on the same support buffers and D.  Same ping-pong contract; wta_out /
     store_right as in cbca_hwd_pair (mccnn_cbca_iter_prog_pair_wta for the last iteration).
@@ -401,13 +425,17 @@ def cbca_prog_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, progs, D, i
     skip_unit_regions: from the SECOND iteration on, pixels whose support region is the pixel itself are left alone
     (mccnn_cbca_iter_prog_pair_skip).  Such a pixel gets v1 = (0 + v0) / 1 in the first iteration (pf:156-161 with
     aver_num = 1), which is v0 except that -0.0 becomes +0.0 and a signalling NaN is quieted, and (0 + v1) / 1 = v1 bit
-    for bit ever after.  The first iteration (full programs) puts v1 into the partner buffer; the input buffer keeps v0.
-    Every later iteration may skip these pixels: as a NEIGHBOUR in somebody else's region v0 and v1 give the same sum
-    bit for bit (a running sum that started as 0 + x is never -0.0, so adding -0.0 or +0.0 cannot differ; a NaN operand
-    gives the same quiet NaN either way), and nothing else reads them - except the caller, from the final buffer.  With
-    an even number of iterations that is the input buffer (v0!), so the last iteration then runs the full programs and
-    rewrites every pixel; with an odd number it is the partner buffer, which has held v1 since the first iteration.
-    The iteration that carries the WTA runs the full programs anyway.  Same bits everywhere, fewer bytes moved.
+    for bit ever after.  The first iteration (full programs) puts v1 into the partner buffer; with refresh_first
+    (default, round 6) and an even number of iterations that would otherwise have to end with a full launch, it is a
+    mccnn_cbca_iter_prog_refresh launch, which also writes v1 back into the input buffer, so that BOTH buffers
+    hold the final value of these pixels and every later iteration may skip them, whichever buffer it writes: as a
+    NEIGHBOUR in somebody else's region v0 and v1 give the same sum bit for bit (a running sum that started as 0 + x is
+    never -0.0, so adding -0.0 or +0.0 cannot differ; a NaN operand gives the same quiet NaN either way), and nothing
+    else reads them - except the caller, from the final buffer.  refresh_first=False is round 5's rule: the input buffer
+    keeps v0, so with an even number of iterations - the result lands in the input buffer - the last iteration runs the
+    full programs and rewrites every pixel.  The iteration that carries the WTA runs the full programs either way.  Same
+    bits everywhere, fewer bytes moved.  NOTE: with refresh_first the INPUT volume is modified (v0 -> v1 at unit-region
+    pixels) whenever a later iteration skips, i.e. for iterations >= 2.
     skip_ready: an event after which the second program set is complete when it was built on another stream (the
     current stream waits for it in front of the first iteration that needs it).
 
@@ -430,10 +458,10 @@ def cbca_prog_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, progs, D, i
     n = int(iterations)
     if wta_out is not None and (n < 1 or D > cbca_hwd_wta_max_d()):
         raise ValueError("cbca_prog_pair: the fused WTA needs at least one iteration and D <= %d" % cbca_hwd_wta_max_d())
+    kinds = skip_schedule(n, wta_out is not None, skip_unit_regions, refresh_first)
+
     def skips(it):
-        # (see the docstring) not the first iteration, and not the one that leaves the result in the input buffer
-        fused_ = wta_out is not None and it == n - 1
-        return bool(skip_unit_regions) and it >= 1 and not fused_ and not (n % 2 == 0 and it == n - 1)
+        return kinds[it] == "skip"
 
     n_chain = 0
     if right_stream is not None:
@@ -452,6 +480,7 @@ def cbca_prog_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, progs, D, i
                         st.wait_event(skip_ready)
                         waited_ = True
                     fn, who = ((lib.mccnn_cbca_iter_prog_skip, "mccnn_cbca_iter_prog_skip") if skip
+                               else (lib.mccnn_cbca_iter_prog_refresh, "mccnn_cbca_iter_prog_refresh") if kinds[it] == "refresh"
                                else (lib.mccnn_cbca_iter_prog, "mccnn_cbca_iter_prog"))
                     timer.start("cbca_iter_prog_skip" if skip else "cbca_iter_prog")
                     hip.check(fn(hip.ptr(src), hip.ptr(dst), hip.ptr(sup), hip.ptr(prog), int(D), H, W,
@@ -476,8 +505,9 @@ def cbca_prog_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, progs, D, i
                                                         hip.ptr(wta_out[1]), 1 if store_right else 0, hip.stream()),
                       "mccnn_cbca_iter_prog_pair_wta")
         else:
-            fn, who = ((lib.mccnn_cbca_iter_prog_pair_skip, "mccnn_cbca_iter_prog_pair_skip")
-                       if skip else (lib.mccnn_cbca_iter_prog_pair, "mccnn_cbca_iter_prog_pair"))
+            fn, who = ((lib.mccnn_cbca_iter_prog_pair_skip, "mccnn_cbca_iter_prog_pair_skip") if skip
+                       else (lib.mccnn_cbca_iter_prog_pair_refresh, "mccnn_cbca_iter_prog_pair_refresh")
+                       if kinds[it] == "refresh" else (lib.mccnn_cbca_iter_prog_pair, "mccnn_cbca_iter_prog_pair"))
             if skip_ready is not None and skip and not waited:
                 torch.cuda.current_stream().wait_event(skip_ready)
                 waited = True
@@ -489,22 +519,24 @@ def cbca_prog_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, progs, D, i
 
 
 def cbca_prog_chain(vol, tmp, support, prog, D, iterations, distance_threshold, first=0, total=None, fused_last=False,
-                    skip_unit_regions=True, skip_ready=None, timer=None):
+                    skip_unit_regions=True, skip_ready=None, timer=None, refresh_first=True):
     """Iterations first .. iterations-1 of ONE volume's aggregation on the current stream (mccnn_cbca_iter_prog /
     _skip; cbca_prog_pair's rule for which iterations leave the unit-region pixels alone, with `total` = the length of
     the whole aggregation and fused_last = its last iteration carries the WTA and is not part of the chain)."""
     H, W, Dp = vol.shape
     lib = hip.load()
     n = int(total if total is not None else iterations)
+    kinds = skip_schedule(n, fused_last, skip_unit_regions, refresh_first)
     src, dst = vol, tmp
     waited = False
     timer = timer or _NO_TIMER
     for it in range(int(first), int(iterations)):
-        skip = bool(skip_unit_regions) and it >= 1 and not (fused_last and it == n - 1) and not (n % 2 == 0 and it == n - 1)
+        skip = kinds[it] == "skip"
         if skip and skip_ready is not None and not waited:
             torch.cuda.current_stream().wait_event(skip_ready)
             waited = True
         fn, who = ((lib.mccnn_cbca_iter_prog_skip, "mccnn_cbca_iter_prog_skip") if skip
+                   else (lib.mccnn_cbca_iter_prog_refresh, "mccnn_cbca_iter_prog_refresh") if kinds[it] == "refresh"
                    else (lib.mccnn_cbca_iter_prog, "mccnn_cbca_iter_prog"))
         timer.start("cbca_iter_prog_skip" if skip else "cbca_iter_prog")
         hip.check(fn(hip.ptr(src), hip.ptr(dst), hip.ptr(support), hip.ptr(prog), int(D), H, W, int(distance_threshold),
@@ -754,7 +786,7 @@ class StereoMatcher(object):
     def __init__(self, net, hp=None, cv_mode=hip.MCCNN_CV_EXACT, cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER,
                  feature_tile_rows=None, extras=None, features="auto", layout="auto", cbca_kernel="auto",
                  on_saturation="fallback", skip_unit_regions=True, two_chains=True, one_launch_builder=True,
-                 side_early=False, free_chains=True):
+                 side_early=False, free_chains=True, refresh_first=True):
         self.device = hip.require_device()
         self.net = net
         self.hp = dict(DEFAULT_HP)
@@ -804,6 +836,10 @@ class StereoMatcher(object):
         # round 5's schedule: the chains join after every stage and the SGM passes are two-volume launches
         self.side_early = bool(side_early)
         self.free_chains = bool(free_chains)
+        # skip_schedule's rule (round 6): an aggregation with an even number of iterations whose last launch carries no WTA
+        # (match.py's first: 2 iterations) starts with a refresh launch and then skips to the end; False = round 5's rule
+        # (its last launch is a full one)
+        self.refresh_first = bool(refresh_first)
         # opt-in departures from the reference (they change the output): the paper's rules it leaves out, and the
         # scalar promotion of the NumPy it was written for
         self.extras = dict(both_view_support=False, interpolation_directions=4, occlusion_from_left=False,
@@ -991,7 +1027,7 @@ class StereoMatcher(object):
                     return cbca_hwd_pair(lh, lt, sup_l, rh, rt, sup_r, D, int(n), hp["cbca_distance"], timer, **kw)
                 return cbca_prog_pair(lh, lt, sup_l, rh, rt, sup_r, progs, D, int(n), hp["cbca_distance"], timer,
                                       skip_ready=skip_ready if overlap else None,
-                                      skip_unit_regions=self.skip_unit_regions,
+                                      skip_unit_regions=self.skip_unit_regions, refresh_first=self.refresh_first,
                                       right_stream=self._right_stream() if self.two_chains else None, **kw)
 
             # free-running chains (default): each volume's aggregation -> SGM -> aggregation is ONE chain of one-volume
@@ -1012,7 +1048,7 @@ class StereoMatcher(object):
                         # (the brackets are recorded on the chain's own stream: a stage's span beside the other chain)
                         timer.span_start("aggregation_1")
                         v, t = cbca_prog_chain(v, t, sup, prog, D, n1, hp["cbca_distance"],
-                                               skip_unit_regions=self.skip_unit_regions,
+                                               skip_unit_regions=self.skip_unit_regions, refresh_first=self.refresh_first,
                                                skip_ready=skip_ready if overlap else None, timer=timer)
                         timer.span_stop("aggregation_1")
                         timer.span_start("sgm")
@@ -1022,6 +1058,7 @@ class StereoMatcher(object):
                         timer.span_start("aggregation_2")
                         v, t = cbca_prog_chain(v, t, sup, prog, D, n2 - 1 if fuse else n2, hp["cbca_distance"], total=n2,
                                                fused_last=fuse, skip_unit_regions=self.skip_unit_regions,
+                                               refresh_first=self.refresh_first,
                                                skip_ready=skip_ready if overlap else None, timer=timer)
                         timer.span_stop("aggregation_2")
                         ends.append((v, t))

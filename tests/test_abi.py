@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol(lib_path):
     for name in header_functions():
         assert hasattr(lib, name), "libmccnn_hip.so lacks %s declared in include/mccnn.h" % name
     lib.mccnn_version.restype = ctypes.c_int
-    assert lib.mccnn_version() == 6
+    assert lib.mccnn_version() == 7
     lib.mccnn_hwd_pitch.restype = ctypes.c_int
     assert [lib.mccnn_hwd_pitch(d) for d in (1, 4, 5, 256, 400)] == [4, 4, 8, 256, 400]
 

@@ -123,7 +123,7 @@ def test_cxx_builder_equals_the_python_statement(tmp_path, vpl, k, w):
                     assert np.array_equal(got[:n], want), (H, W, y0, x0, skip)
 
 
-def simulate(g, L, img, vol, code_addr=0x7e00fffff000, out_init=None):
+def simulate(g, L, img, vol, code_addr=0x7e00fffff000, out_init=None, return_in=False):
     """Runs every workgroup of one single-volume launch of the generated kernel in the simulator.  The skip kernel
     (g.P.skip) runs the skip programs; out_init [D, H, W] is then what the output buffer holds beforehand."""
     P = g.P
@@ -162,6 +162,9 @@ def simulate(g, L, img, vol, code_addr=0x7e00fffff000, out_init=None):
                 for k in tot:
                     tot[k] += st[k]
     out = mem.get(a_out, np.float32, H * W * Dp).reshape(H, W, Dp)[:, :, :D]
+    if return_in:
+        vin = mem.get(a_in, np.float32, H * W * Dp).reshape(H, W, Dp)[:, :, :D]
+        return out.transpose(2, 0, 1), tot, vin.transpose(2, 0, 1)
     return out.transpose(2, 0, 1), tot
 
 
@@ -296,9 +299,78 @@ def test_unit_regions_are_fixed_points_after_one_iteration_including_negative_ze
     assert np.array_equal(v1[:, unit][~nan & (vol[:, unit] != 0)], vol[:, unit][~nan & (vol[:, unit] != 0)])
 
 
+def _skip_schedule():
+    """stereo_device.skip_schedule without importing torch: the function is pure Python."""
+    src = open(os.path.join(ROOT, "mc-cnn-python_amd", "src", "stereo_device.py")).read()
+    ns = {}
+    exec(src[src.index("def skip_schedule"):src.index("def cbca_prog_pair")], ns)
+    return ns["skip_schedule"]
+
+
+def _canon(a):
+    u = a.view(np.uint32).copy()
+    u[np.isnan(a)] = 0x7fc00000
+    return u
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 16])
+def test_refresh_schedule_equals_the_oracle(n, fused):
+    """stereo_device.skip_schedule (round 6) restated on the CPU checker: "refresh" = a full iteration that also writes
+    v1 = (0 + v0) / 1 of every unit-region pixel back into its INPUT buffer (the kernel's store races with neighbours that
+    read the pixel: modelled here by running the iteration on the input with v1 ALREADY in place, and on the input as
+    it was - both must give the same bits), "skip" leaves the unit-region pixels of its destination alone, "wta" / "full"
+    write everything.  With -0.0 / inf / NaN / subnormals on such pixels the final buffer equals n iterations of
+    pf:149-163 bit for bit whichever buffer the last iteration writes."""
+    kinds = _skip_schedule()(n, fused)
+    assert len(kinds) == n and ("refresh" not in kinds[1:]) and (kinds[-1] == "wta") == fused
+    img, vol = make_case(24, 32, 6, 3)
+    unit = (support_words(img) & 0xfffff) == 0
+    assert unit.any() and not unit.all()
+    vol[:, unit] = np.resize(np.array([-0.0, 0.0, np.inf, -np.inf, np.nan, 1e-42, -1e-42, 1.5, -0.0], np.float32),
+                             vol[:, unit].shape)
+    want = vol
+    for _ in range(n):
+        want = oracle_cbca(img, want)
+    bufs = [vol.copy(), np.full_like(vol, 12345.0)]
+    for it, kind in enumerate(kinds):
+        src, dst = bufs[it % 2], bufs[1 - it % 2]
+        res = oracle_cbca(img, src)
+        if kind == "refresh":
+            refreshed = src.copy()
+            refreshed[:, unit] = res[:, unit]
+            again = oracle_cbca(img, refreshed)           # what a wave computes that reads the already rewritten pixels
+            assert np.array_equal(_canon(again), _canon(res))
+            bufs[it % 2] = refreshed
+        if kind == "skip":
+            res[:, unit] = dst[:, unit]
+        bufs[1 - it % 2] = res
+    got = bufs[n % 2]
+    assert np.array_equal(_canon(got), _canon(want))
+    if n >= 2 and n % 2 == 0 and not fused:               # the case the refresh launch exists for
+        assert kinds[0] == "refresh" and set(kinds[1:]) == {"skip"}
+
+
+def test_refresh_kernel_in_the_simulator():
+    """The generated refresh kernel: the oracle's bits in `out`, and in `in` v1 at every unit-region pixel (-0.0 became
+    +0.0 there) with every other input voxel untouched."""
+    g = gen.Gen(gen.Params(vpl=4, K=4, W=20, refresh=True)).build()
+    L = g.layout()
+    img, vol = make_case(24, 32, 6, 3)
+    unit = (support_words(img) & 0xfffff) == 0
+    vol[:, unit] = np.resize(np.array([-0.0, 0.0, np.inf, -np.inf, np.nan, 1e-42, -1e-42, 1.5, -0.0], np.float32),
+                             vol[:, unit].shape)
+    want = oracle_cbca(img, vol)
+    got, _, vin = simulate(g, L, img, vol, return_in=True)
+    assert_bits_strict(got, want, "refresh kernel, output")
+    assert_bits_strict(vin[:, unit], want[:, unit], "refresh kernel, unit-region pixels of the input")
+    assert np.array_equal(vin[:, ~unit].view(np.uint32), vol[:, ~unit].view(np.uint32))
+    assert (np.signbit(vol[:, unit]) & (vol[:, unit] == 0)).any() and not (np.signbit(vin[:, unit]) & (vin[:, unit] == 0)).any()
+
+
 @pytest.mark.parametrize("n", [2, 3, 4, 5, 16])
 def test_skipping_from_the_second_iteration_on_equals_the_oracle(n):
-    """The schedule stereo_device.cbca_prog_pair runs, restated on the CPU checker: iteration 1 full (in -> out), every
+    """Round 5's schedule (skip_schedule(refresh_first=False)), restated on the CPU checker: iteration 1 full (in -> out), every
     later iteration leaves the unit-region pixels of its destination as they are - v1 in `out`, the ORIGINAL v0 in `in` -
     and an even count ends with a full iteration.  With -0.0 / inf / NaN / subnormals on such pixels the final buffer
     equals n iterations of pf:149-163 bit for bit: as an operand of another pixel's sum v0 and v1 are interchangeable."""
