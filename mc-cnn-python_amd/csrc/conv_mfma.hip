@@ -42,6 +42,9 @@ typedef float f16x __attribute__((ext_vector_type(16)));
 typedef uint32_t w4 __attribute__((ext_vector_type(4)));
 typedef uint32_t w2 __attribute__((ext_vector_type(2)));
 
+#ifndef CONV_STAGE_TAP
+#define CONV_STAGE_TAP 0                     // the tap behind whose fragment loads the next group's activations are requested (-1: in front of tap 0)
+#endif
 #ifndef CONV_NBW
 #define CONV_NBW 4                           // rows of 32 pixels per wave (4: one workgroup per CU; 2: two)
 #endif
@@ -279,16 +282,22 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            // next channel group of this tile, or group 0 of the next tile, into registers
-            if (q < 3)
-                fetch(n, ty0, tx0, q + 1);
-            else
-                fetch(nn, nty0, ntx0, 0);
+            // next channel group of this tile, or group 0 of the next tile, into registers: issued BEHIND the first tap's
+            // weight-fragment loads (CONV_STAGE_TAP, round 6) - vector-memory loads retire in order, so the first
+            // fragment wait behind these loads waits out their HBM latency; one tap later they have three K steps to land
+            // instead of two.
             // Loads stay where they are written: without the compiler-level memory barrier instruction selection
             // places these (unchained, read-only) loads next to their first use, and without the scheduling barrier
             // (vector-memory instructions may not cross, everything else may) the scheduler sinks them there - either
             // way the prefetch is gone.
-            pin_loads();
+            auto stage_next = [&]() {
+                if (q < 3)
+                    fetch(n, ty0, tx0, q + 1);
+                else
+                    fetch(nn, nty0, ntx0, 0);
+                pin_loads();
+            };
+            if (CONV_STAGE_TAP < 0) stage_next();
             const char *bq = lds + (q & 1) * QBUF + bfrag;
             char *const other = lds + ((q + 1) & 1) * QBUF;
             // B fragments one step (= one row of 32 pixels at one tap, 6 MFMAs) ahead: the wave issues in order, so a
@@ -307,6 +316,7 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const char *__restri
                 const int ks = q * 9 + tap;
                 fetch_a((ks + NSLOT - 1) % NSLOT, (ks + NSLOT - 1) % 36);
                 pin_loads();
+                if (tap == CONV_STAGE_TAP) stage_next();
                 const int slot = ks % NSLOT;
                 const h8 a_hi0 = __builtin_bit_cast(h8, af[slot][0]), a_hi1 = __builtin_bit_cast(h8, af[slot][1]);
                 const h8 a_lo0 = __builtin_bit_cast(h8, af[slot][2]), a_lo1 = __builtin_bit_cast(h8, af[slot][3]);
