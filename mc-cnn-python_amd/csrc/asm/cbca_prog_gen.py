@@ -944,7 +944,7 @@ class Gen:
                 if P.refresh:       # a unit region: its value v1 also replaces v0 in the input buffer
                     e("s_and_b32", s("t0"), sreg(S["cnt"] + k * G + j), 0xfffff)
                     e("s_cbranch_scc1", "norefresh_%d_%d" % (k, j))
-                    self.vstore(P.acc(k, j), P.v_voff, S["rs_ref"], s("so"))
+                    self.vstore(P.acc(k, j), P.v_voff, S["rs_ref"], s("so"), nt=True)   # (nt: -1.3 % of the stage, B.5)
                     e("s_nop", 0, comment="gfx950 store-data hazard (common.h)")
                     self.label("norefresh_%d_%d" % (k, j))
                 if P.skip:
