@@ -188,6 +188,14 @@ def test_bench_world_size_one_through_rccl():
     assert d["parity"]["final_map_bit_identical"] and d["parity"]["timed_path_equals_kernel_by_kernel"]
     assert d["parity_violations"] == [] and d["fast_variant_ms_per_step"] > 0
     assert d["fast_variant_parity"]["violations"] == [], d["fast_variant_parity"]
+    # round 6: the schedule's side numbers, the natural-statistics scene, pairs in flight, per-chain stage brackets
+    assert d["ms_per_step_chains_joined_after_every_stage"] > 0 and d["natural_scene_ms_per_step"] > 0
+    assert d["natural_scene"]["unit_region_pixels"]["left"] > 0.8 > d["unit_region_pixels"]["left"]
+    for key in ("ms_per_pair_two_in_flight", "ms_per_pair_four_in_flight"):
+        assert d[key]["ms_per_pair"] > 0 and d[key]["final_map_equals_the_timed_pair"], d[key]
+    assert d["aggregation_stages"]["aggregation_1"]["skip_iterations"] == 1          # refresh, skip
+    assert d["aggregation_stages"]["aggregation_2"]["skip_iterations"] == 14         # full, 14 x skip, full + WTA
+    assert d["rooflines"]["sgm_pass_one_volume"]["concurrent_launches"] == 2 and d["sgm_stage"]["ms"] > 0
     assert len(d["per_rank_device"]) == 1 and d["per_rank_device"][0]["device"] == 0
     want = 256 * 256 * 64 * 1e-6 / (d["ms_per_step"] * 1e-3)
     assert abs(d["value"] - want) <= 0.02 * want

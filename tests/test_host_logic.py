@@ -250,6 +250,32 @@ def test_synthetic_pairs_are_deterministic_and_standardised():
     assert a[2].dtype == np.uint8 and len(np.unique(a[2])) > 8
 
 
+def test_synthetic_scene_classes():
+    """The three seeded scene classes bench.py times (synthetic.SCENE_KINDS): the default recipe, its texture-free variant
+    (= texture=False) and the 1/f-spectrum "natural" picture; what distinguishes them for the aggregation is the share of
+    pixels whose support region is the pixel itself (pf:580-629 with match.py's threshold 0.02 on the standardised image)."""
+    import oracle as o
+    import synthetic
+    assert synthetic.SCENE_KINDS == ("blobs+texture", "flat", "natural")
+    H, W, D = 96, 128, 16
+    unit = {}
+    for kind in synthetic.SCENE_KINDS:
+        L, R, lu, ru, dmap = synthetic.make_pair(H, W, D, seed=7, kind=kind)
+        L2 = synthetic.make_pair(H, W, D, seed=7, kind=kind)[0]
+        assert np.array_equal(L, L2) and L.shape == (H, W, 1) and lu.dtype == np.uint8 and dmap.shape == (H, W)
+        assert abs(float(L.mean())) < 1e-5 and abs(float(L.std()) - 1.0) < 1e-4
+        _, cnt = o.cross_arms(L, 0.02, 14)
+        unit[kind] = float((cnt == 1).mean())
+    assert np.array_equal(synthetic.make_pair(H, W, D, seed=7, texture=False)[0], synthetic.make_pair(H, W, D, seed=7, kind="flat")[0])
+    assert np.array_equal(synthetic.make_pair(H, W, D, seed=7)[0], synthetic.make_pair(H, W, D, seed=7, kind="blobs+texture")[0])
+    assert unit["flat"] < 0.05 < unit["blobs+texture"] < 0.8 < unit["natural"], unit
+    with pytest.raises(ValueError):
+        synthetic.make_pair(H, W, D, kind="photograph")
+    # 8-bit picture with a photograph's contrast (std 40-60 grey levels before standardisation)
+    nat = synthetic.natural_scene_u8(H, W, seed=1)
+    assert nat.dtype == np.uint8 and 35.0 < float(nat.std()) < 60.0
+
+
 def test_shard_indices_cover_window_once():
     from distributed import shard_indices
     for world in (1, 2, 3, 8):
