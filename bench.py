@@ -378,7 +378,6 @@ def main():
     # running sums (pf:157-161) at their longest: the aggregation is then bound by its additions, not by bytes.
     noskip_ms = worst_ms = worst_unit = joined_ms = natural_ms = natural_unit = None
     in_flight = {}
-    voxels_hint = H * W * D
     if not args.no_bounds and matcher.pixel_major() and matcher.workspace(H, W, D)["progs"] is not None:
         # round 5's launch structure (StereoMatcher(free_chains=False)): the two chains of one-volume aggregation launches
         # join after every stage and the SGM passes are two-volume launches; same bits
@@ -417,7 +416,7 @@ def main():
         # captured graph, replayed round-robin on N streams.  Outside `value` (the headline stays one pair per GPU).
         for n_fl in (2, 4):
             free_b, _total_b = torch.cuda.mem_get_info()
-            need = n_fl * 6.5 * 4.0 * voxels_hint                      # ~4 volumes + programs + conv activations each
+            need = n_fl * 6.5 * 4.0 * H * W * D                        # ~4 volumes + programs + conv activations each
             if need > 0.8 * free_b:
                 continue
             ms_ = [sd.StereoMatcher(net, cv_mode=matcher.cv_mode, cbca_order=matcher.cbca_order, features=matcher.features,

@@ -434,8 +434,9 @@ def cbca_prog_pair(vol_l, tmp_l, support_l, vol_r, tmp_r, support_r, progs, D, i
     else reads them - except the caller, from the final buffer.  refresh_first=False is round 5's rule: the input buffer
     keeps v0, so with an even number of iterations - the result lands in the input buffer - the last iteration runs the
     full programs and rewrites every pixel.  The iteration that carries the WTA runs the full programs either way.  Same
-    bits everywhere, fewer bytes moved.  NOTE: with refresh_first the INPUT volume is modified (v0 -> v1 at unit-region
-    pixels) whenever a later iteration skips, i.e. for iterations >= 2.
+    bits everywhere, fewer bytes moved.  NOTE: a refresh launch modifies the INPUT volume (v0 -> v1 at unit-region
+    pixels); skip_schedule issues one only for an even number of iterations without a fused WTA - where the input buffer
+    is also the result buffer, which holds v1 there in the end either way.
     skip_ready: an event after which the second program set is complete when it was built on another stream (the
     current stream waits for it in front of the first iteration that needs it).
 

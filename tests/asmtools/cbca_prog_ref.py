@@ -399,7 +399,6 @@ def build_tile_programs(sup0, H, W, y0, tx, L, skip_unit=False):
                     emit(w, nop)
             emit(w, L["step"] | (nslots << 16))
             emit(w, p)
-            assert len(progs[w]) % 64 != 0 or True
             units = []
             plan_row(sup0, W, yq, row0, x0t + w * G, aset[w * G:(w + 1) * G], L, units)
             for lo, hi, _, runs, _ in units:
