@@ -205,9 +205,14 @@ class Params:
         if tile:
             self.SLOTS = tile * G + 2 * R                 # LDS slots of a region row: the tile's columns + both longest arms
             self.SB = 256 * vpl                           # bytes of a slot (64 lanes x vpl floats)
-            assert self.SLOTS * self.SB <= 65536, "the LDS address of a slot travels in M0[15:0]"
-            self.v_lane16, self.v_lds = self.nvgpr, self.nvgpr + 1
-            self.nvgpr += 2
+            # buffer_load ... lds exists for 4, 12 and 16 bytes per lane: a request is always 64 lanes x 16 bytes = 1 KiB,
+            # i.e. SPD = 1 slot at four disparities per lane, 2 consecutive slots (pixels) at two
+            assert vpl in (2, 4), "tile: 16-byte LDS requests cover whole slots at 2 or 4 disparities per lane"
+            self.SPD = 1024 // self.SB
+            self.LDS_BYTES = (self.SLOTS + self.SPD - 1) * self.SB    # (an odd row's last request writes one slot more)
+            assert self.LDS_BYTES <= 65536, "the LDS address of a slot travels in M0[15:0]"
+            self.v_lane16, self.v_lds, self.v_dma = self.nvgpr, self.nvgpr + 1, self.nvgpr + 2
+            self.nvgpr += 3 if self.SPD > 1 else 2
             self.nvgpr_alloc = max(self.nvgpr, minvgpr)
 
     def acc(self, k, j, c=0):
@@ -578,6 +583,18 @@ class Gen:
         e("v_mov_b32", vreg(P.v_voff), KDROP)
         e("v_cmp_gt_u32", "vcc", s("pix"), vreg(vt))
         e("v_cndmask_b32", vreg(P.v_voff), vreg(P.v_voff), vreg(vt), "vcc")
+        if P.tile and P.SPD > 1:
+            # LDS requests are 16 bytes per lane: lanes 0-31 fetch pixel p, lanes 32-63 pixel p + 1 (two consecutive slots)
+            e("v_and_b32", vreg(vt), 31, "v0")
+            e("v_lshlrev_b32", vreg(vt), 4, vreg(vt))
+            e("s_mul_i32", s("t1"), s("chunk"), 64 * 4 * VPL)
+            e("v_add_u32", vreg(vt), s("t1"), vreg(vt), comment="byte offset inside the pixel's record")
+            e("v_cmp_gt_u32", "vcc", s("pix"), vreg(vt))
+            e("v_lshrrev_b32", vreg(P.v_dma), 5, "v0")
+            e("v_mul_u32_u24", vreg(P.v_dma), s("pix"), vreg(P.v_dma))
+            e("v_add_u32", vreg(P.v_dma), vreg(P.v_dma), vreg(vt))
+            e("v_mov_b32", vreg(vt), KDROP)
+            e("v_cndmask_b32", vreg(P.v_dma), vreg(vt), vreg(P.v_dma), "vcc")
         if P.PF:
             self.prefetch()
         # input rows row0 .. row1 any arm of this patch can reach: descriptor base = in + row0 * W * pix
@@ -705,25 +722,25 @@ class Gen:
             e("s_lshr_b32", s("st_n"), s("op"), 16)
             e("v_readlane_b32", s("so"), vreg(P.v_progA), s("i"))
             e("s_add_u32", s("i"), s("i"), 1)
-            e("s_add_u32", s("so"), s("so"), s("wave"))
+            SPD = P.SPD                                                  # slots one request fills
+            e("s_mul_i32", s("st_s"), s("wave"), SPD)
+            e("s_add_u32", s("so"), s("so"), s("st_s"))
             e("s_mul_i32", s("so"), s("so"), s("pix"))
-            e("s_mul_i32", s("st_lds"), s("wave"), SB)
-            e("s_mul_i32", s("st_str"), s("pix"), P.tile)
-            e("s_mov_b32", s("st_s"), s("wave"))
+            e("s_mul_i32", s("st_lds"), s("st_s"), SB)
+            e("s_mul_i32", s("st_str"), s("pix"), P.tile * SPD)
             e("s_set_gpr_idx_off")
             e("s_barrier")
             self.label("step_loop")
             e("s_cmp_ge_u32", s("st_s"), s("st_n"))
             e("s_cbranch_scc1", "step_done")
             e("s_mov_b32", "m0", s("st_lds"))
-            op = {1: "buffer_load_dword", 2: "buffer_load_dwordx2", 3: "buffer_load_dwordx3", 4: "buffer_load_dwordx4"}[VPL]
             if not (P.debug & 32):                                       # debug 32 (fault hunting): no requests
-                e(op, vreg(P.v_voff), s("rs_in", 4), s("so"), offen=True, lds=True)
+                e("buffer_load_dwordx4", vreg(P.v_voff if SPD == 1 else P.v_dma), s("rs_in", 4), s("so"), offen=True, lds=True)
             else:
                 e("s_nop", 0)
                 e("s_nop", 0)
-            e("s_add_u32", s("st_s"), s("st_s"), P.tile)
-            e("s_add_u32", s("st_lds"), s("st_lds"), P.tile * SB)
+            e("s_add_u32", s("st_s"), s("st_s"), P.tile * SPD)
+            e("s_add_u32", s("st_lds"), s("st_lds"), P.tile * SPD * SB)
             e("s_add_u32", s("so"), s("so"), s("st_str"))
             e("s_branch", "step_loop")
             self.label("step_done")
@@ -1129,7 +1146,7 @@ class Gen:
                 line = re.sub(r"\b(code_base|after_getpc|done|pf_done|pf_loop\d+|load_b\d+_blk\d+|loadblk_\d+|loadnt_blk\d+|load_done|loadf_blk\d+|h_end|h_load1|h_loadf1|first_is_end|nodiv_\d+_\d+|nostore_\d+_\d+|norefresh_\d+_\d+|pf_blk\d+|cp_blk\d+|loadl_blk\d+|step_loop|step_done|p_div|p_divd|p_z|p_patch|p_nextz|e_nofetch)\b", lambda m: ".L%s_%s" % (name, m.group(1)), line)
                 out.append(line)
         kargs = 0x80 if (P.wta or P.persist) else 0x60
-        lds_bytes = P.SLOTS * P.SB if P.tile else P.ring * 256 * P.VPL
+        lds_bytes = P.LDS_BYTES if P.tile else P.ring * 256 * P.VPL
         wg = 64 * P.tile if P.tile else 64
         out += [".Lfunc_end_%s:" % name, ".size %s, .Lfunc_end_%s-%s" % (name, name, name), "",
                 ".rodata", ".p2align 6", ".amdhsa_kernel %s" % name,

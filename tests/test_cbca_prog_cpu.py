@@ -201,7 +201,7 @@ def simulate_tile(g, L, img, vol, out_init=None):
         for by in range(meta["ntx"]):
             for bz in range(nchunks):
                 st = asm_sim.run_workgroup(g, mem, P.tile, {0: a_k & 0xffffffff, 1: a_k >> 32, 2: bx, 3: by, 4: bz}, P.nvgpr,
-                                           P.SLOTS * P.SB)
+                                           P.LDS_BYTES)
                 for k, v in st.items():
                     tot[k] = tot.get(k, 0) + v
     out = mem.get(a_out, np.float32, H * W * Dp).reshape(H, W, Dp)[:, :, :D]

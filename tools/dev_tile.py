@@ -63,7 +63,7 @@ def tile_programs(sup, H, W, L, Dp):
     return out, meta
 
 
-def check_small(mods, L, nw, H, W, D, seed, n_iter=3):
+def check_small(mods, L, nw, H, W, D, seed, n_iter=3, vpl=4):
     """n_iter iterations (full, skip.., full when even) of the tile kernels against cbca_prog_pair on a small shape."""
     Li = synthetic.make_pair(H, W, max(1, min(D, W - 2)), seed=seed)[0]
     img = torch.from_numpy(Li[:, :, 0]).cuda()
@@ -78,7 +78,7 @@ def check_small(mods, L, nw, H, W, D, seed, n_iter=3):
     torch.cuda.synchronize()
     print("   reference done", flush=True)
     (pf, ps), meta = tile_programs(sup, H, W, L, Dp)
-    nchunks = -(-Dp // 256)
+    nchunks = -(-Dp // (64 * vpl))
     grid = (8 * meta["band_groups"], meta["ntx"], nchunks)
     x, y = a.clone(), torch.full_like(a, float("nan"))
     for it in range(n_iter):
@@ -105,23 +105,25 @@ def main():
     ap.add_argument("--reps", type=int, default=10); ap.add_argument("--nw", type=int, default=4)
     ap.add_argument("--small-only", action="store_true")
     ap.add_argument("--debug", type=int, default=0, help="generator debug bits (32: no LDS requests, 64: no LDS reads)")
+    ap.add_argument("--vpl", type=int, default=4, help="disparities per lane (2: 128-disparity chunks, 512-byte LDS slots, 86 VGPRs)")
     args = ap.parse_args()
     global DEBUG
     DEBUG = args.debug
     hip.require_device()
     H, W, D = CONFIGS[args.config]
     Dp = sd.hwd_pitch(D)
-    assert Dp % 4 == 0 and (Dp > 192 or args.small_only), "the prototype is assembled for four disparities per lane"
+    VPL = args.vpl
+    assert Dp % VPL == 0 and VPL in (2, 4)
     outdir = os.path.join(ROOT, "mc-cnn-python_amd", "build", "asm")
     mods = {}
     for skip in (False, True):
-        g, mods[skip] = assemble(4, args.nw, skip, outdir)
+        g, mods[skip] = assemble(VPL, args.nw, skip, outdir)
         L = g.layout()
-    print("tile kernel: %d waves per workgroup, %d VGPRs, %d bytes of LDS, %d bytes of code" % (args.nw, g.P.nvgpr, g.P.SLOTS * g.P.SB,
+    print("tile kernel: %d waves per workgroup, %d VGPRs, %d bytes of LDS, %d bytes of code" % (args.nw, g.P.nvgpr, g.P.LDS_BYTES,
                                                                                                L["code_bytes"]), flush=True)
     ok = True
     for (h, w, d, seed, n) in ((24, 32, 256, 1, 3), (37, 61, 256, 2, 4), (40, 203, 300, 3, 5), (9, 44, 256, 4, 1)):
-        ok &= check_small(mods, L, args.nw, h, w, d, seed, n)
+        ok &= check_small(mods, L, args.nw, h, w, d, seed, n, VPL)
     if args.small_only:
         print("ALL OK" if ok else "FAILED")
         sys.exit(0 if ok else 1)
@@ -139,7 +141,7 @@ def main():
     for sup in (sl, sr):
         pp, meta = tile_programs(sup, H, W, L, Dp)
         tprogs.append(pp)
-    nchunks = -(-Dp // 256)
+    nchunks = -(-Dp // (64 * VPL))
     grid = (8 * meta["band_groups"], meta["ntx"], nchunks)
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
 
