@@ -263,6 +263,15 @@ size_t mccnn_sgm_scratch_bytes(int H, int W, int D);
 int mccnn_sgm_pass(const float *image_left, const float *image_right, float *const *vol_hwd, const int *side,
                    int n_jobs, int D, int H, int W, int rh, int rw, float p1, float p2, float q1, float q2, float thr,
                    void *scratch, size_t scratch_bytes, mccnn_stream_t stream);
+/* The two halves of mccnn_sgm_pass as calls of their own (ABI 7, round 6).  The flag planes (pf:504-533: which pixels'
+ * intensity step along r reaches thr) depend on the two images, r and thr only: mccnn_sgm_flags writes them into `flags`
+ * (>= mccnn_sgm_scratch_bytes(H,W,D)), mccnn_sgm_pass_flagged is the pass itself on planes built for the same H, W, D
+ * and r.  A caller that advances the two volumes of a pair in separate launches (StereoMatcher: two free-running chains
+ * on two streams) builds the planes of each direction once, off the critical path, and both chains read them. */
+int mccnn_sgm_flags(const float *image_left, const float *image_right, int D, int H, int W, int rh, int rw, float thr,
+                    void *flags, size_t flags_bytes, mccnn_stream_t stream);
+int mccnn_sgm_pass_flagged(float *const *vol_hwd, const int *side, int n_jobs, int D, int H, int W, int rh, int rw, float p1,
+                           float p2, float q1, float q2, const void *flags, size_t flags_bytes, mccnn_stream_t stream);
 
 /* The first direction of SGM_average, r = (0,1) (pf:194-195, 216-217), fused with the layout change: reads the
  * plane-major volumes vol_dhw[j] (left untouched) and writes the pixel-major vol_hwd[j], i.e. it replaces

@@ -575,38 +575,54 @@ extern "C" size_t mccnn_sgm_scratch_bytes(int H, int W, int D)
     return 2 * (size_t)H * pitch + 256;  // one flag plane per image
 }
 
-extern "C" int mccnn_sgm_pass(const float *image_left, const float *image_right, float *const *vol_hwd, const int *side,
-                              int n_jobs, int D, int H, int W, int rh, int rw, float p1, float p2, float q1, float q2,
-                              float thr, void *scratch, size_t scratch_bytes, mccnn_stream_t stream)
+// The flag planes of one direction (both images) into `flags` (layout of the scratch buffer of mccnn_sgm_pass).
+static int sgm_launch_flags(const char *who, const float *image_left, const float *image_right, int D, int H, int W, int rh,
+                            int rw, float thr, void *flags, size_t flags_bytes, hipStream_t s)
 {
     using namespace mccnn;
-    MCCNN_REQUIRE(image_left && image_right && vol_hwd && side && scratch, MCCNN_E_INVALID,
-                  "mccnn_sgm_pass: null pointer");
-    MCCNN_REQUIRE(n_jobs == 1 || n_jobs == 2, MCCNN_E_INVALID, "mccnn_sgm_pass: n_jobs=%d must be 1 or 2", n_jobs);
-    MCCNN_REQUIRE(H > 0 && W > 0, MCCNN_E_INVALID, "mccnn_sgm_pass: non-positive size");
+    MCCNN_REQUIRE(image_left && image_right && flags, MCCNN_E_INVALID, "%s: null pointer", who);
+    MCCNN_REQUIRE(H > 0 && W > 0, MCCNN_E_INVALID, "%s: non-positive size", who);
     MCCNN_REQUIRE(D >= 2 && D <= 512, MCCNN_E_UNSUPPORTED,
-                  "mccnn_sgm_pass: D=%d outside [2,512] (the reference itself needs D >= 2, pf:550)", D);
+                  "%s: D=%d outside [2,512] (the reference itself needs D >= 2, pf:550)", who, D);
     MCCNN_REQUIRE((rh == 0 && (rw == 1 || rw == -1)) || (rw == 0 && (rh == 1 || rh == -1)), MCCNN_E_INVALID,
-                  "mccnn_sgm_pass: r=(%d,%d) is not an axis-aligned unit step (pf:484)", rh, rw);
-    MCCNN_REQUIRE(scratch_bytes >= mccnn_sgm_scratch_bytes(H, W, D), MCCNN_E_SCRATCH,
-                  "mccnn_sgm_pass: scratch %zu < %zu bytes", scratch_bytes, mccnn_sgm_scratch_bytes(H, W, D));
-    hipStream_t s = (hipStream_t)stream;
+                  "%s: r=(%d,%d) is not an axis-aligned unit step (pf:484)", who, rh, rw);
+    MCCNN_REQUIRE(flags_bytes >= mccnn_sgm_scratch_bytes(H, W, D), MCCNN_E_SCRATCH, "%s: scratch %zu < %zu bytes", who,
+                  flags_bytes, mccnn_sgm_scratch_bytes(H, W, D));
     const int pad = flag_pad(D);
     const int pitch = W + 2 * pad;
-    uint8_t *plane_l = reinterpret_cast<uint8_t *>(scratch);
+    uint8_t *plane_l = reinterpret_cast<uint8_t *>(flags);
     uint8_t *plane_r = plane_l + (((size_t)H * pitch + 127) & ~(size_t)127);
     const dim3 fgrid(cdiv(pitch, 256), H, 2), fblock(256);
     hipLaunchKernelGGL(sgm_flags_kernel, fgrid, fblock, 0, s, image_left, image_right, H, W, rh, rw, thr, pitch, pad,
                        plane_l, plane_r);
-    int rc = check_launch("mccnn_sgm_pass(flags)");
-    if (rc) return rc;
+    return check_launch(who);
+}
 
+// One direction on 1 or 2 volumes with the flag planes already in `flags`.
+static int sgm_launch_pass(const char *who, float *const *vol_hwd, const int *side, int n_jobs, int D, int H, int W, int rh,
+                           int rw, float p1, float p2, float q1, float q2, const void *flags, size_t flags_bytes,
+                           hipStream_t s)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(vol_hwd && side && flags, MCCNN_E_INVALID, "%s: null pointer", who);
+    MCCNN_REQUIRE(n_jobs == 1 || n_jobs == 2, MCCNN_E_INVALID, "%s: n_jobs=%d must be 1 or 2", who, n_jobs);
+    MCCNN_REQUIRE(H > 0 && W > 0, MCCNN_E_INVALID, "%s: non-positive size", who);
+    MCCNN_REQUIRE(D >= 2 && D <= 512, MCCNN_E_UNSUPPORTED,
+                  "%s: D=%d outside [2,512] (the reference itself needs D >= 2, pf:550)", who, D);
+    MCCNN_REQUIRE((rh == 0 && (rw == 1 || rw == -1)) || (rw == 0 && (rh == 1 || rh == -1)), MCCNN_E_INVALID,
+                  "%s: r=(%d,%d) is not an axis-aligned unit step (pf:484)", who, rh, rw);
+    MCCNN_REQUIRE(flags_bytes >= mccnn_sgm_scratch_bytes(H, W, D), MCCNN_E_SCRATCH, "%s: scratch %zu < %zu bytes", who,
+                  flags_bytes, mccnn_sgm_scratch_bytes(H, W, D));
+    const int pad = flag_pad(D);
+    const int pitch = W + 2 * pad;
+    const uint8_t *plane_l = reinterpret_cast<const uint8_t *>(flags);
+    const uint8_t *plane_r = plane_l + (((size_t)H * pitch + 127) & ~(size_t)127);
     SgmParams P;
     for (int j = 0; j < 2; ++j) {
         const int jj = j < n_jobs ? j : 0;
-        MCCNN_REQUIRE(vol_hwd[jj] != nullptr, MCCNN_E_INVALID, "mccnn_sgm_pass: null volume");
+        MCCNN_REQUIRE(vol_hwd[jj] != nullptr, MCCNN_E_INVALID, "%s: null volume", who);
         MCCNN_REQUIRE(side[jj] == MCCNN_SIDE_LEFT || side[jj] == MCCNN_SIDE_RIGHT, MCCNN_E_INVALID,
-                      "mccnn_sgm_pass: side must be MCCNN_SIDE_LEFT or MCCNN_SIDE_RIGHT");
+                      "%s: side must be MCCNN_SIDE_LEFT or MCCNN_SIDE_RIGHT", who);
         P.job[j].vol = vol_hwd[jj];
         const bool left = side[jj] == MCCNN_SIDE_LEFT;
         P.job[j].aplane = left ? plane_l : plane_r;
@@ -620,7 +636,7 @@ extern "C" int mccnn_sgm_pass(const float *image_left, const float *image_right,
     if ((rh == 0 ? W : H) < 2) return 0;  // nothing to scan
     const dim3 grid(nlines, n_jobs), block(64);
     MCCNN_REQUIRE((size_t)H * W * P.Dp * 4 < ((size_t)1 << 32), MCCNN_E_UNSUPPORTED,
-                  "mccnn_sgm_pass: %dx%dx%d volume exceeds the 4 GiB reach of a buffer descriptor", W, H, D);
+                  "%s: %dx%dx%d volume exceeds the 4 GiB reach of a buffer descriptor", who, W, H, D);
     // steps in flight: 8, 12 and 16 measure the same at 750x500x256 (0.30 / 0.29 ms per pass: 1000-1500 scanline waves);
     // a 1242x375 pair has only 750 row scanlines - fewer waves than SIMDs - and its horizontal passes gain from 24 steps
     // (0.388 -> 0.342 ms); two disparity groups per lane (D > 256) take 12 (vertical 2.17 -> 2.06 ms at 1500x1000x400)
@@ -642,7 +658,40 @@ extern "C" int mccnn_sgm_pass(const float *image_left, const float *image_right,
         hipLaunchKernelGGL((sgm_pass_kernel<2, SGM_PF_2G, true>), grid, block, 0, s, P);
     else
         hipLaunchKernelGGL((sgm_pass_kernel<2, SGM_PF_2G, false>), grid, block, 0, s, P);
-    return check_launch("mccnn_sgm_pass");
+    return check_launch(who);
+}
+
+extern "C" int mccnn_sgm_pass(const float *image_left, const float *image_right, float *const *vol_hwd, const int *side,
+                              int n_jobs, int D, int H, int W, int rh, int rw, float p1, float p2, float q1, float q2,
+                              float thr, void *scratch, size_t scratch_bytes, mccnn_stream_t stream)
+{
+    using namespace mccnn;
+    MCCNN_REQUIRE(image_left && image_right && vol_hwd && side && scratch, MCCNN_E_INVALID,
+                  "mccnn_sgm_pass: null pointer");
+    MCCNN_REQUIRE(n_jobs == 1 || n_jobs == 2, MCCNN_E_INVALID, "mccnn_sgm_pass: n_jobs=%d must be 1 or 2", n_jobs);
+    const int rc = sgm_launch_flags("mccnn_sgm_pass", image_left, image_right, D, H, W, rh, rw, thr, scratch, scratch_bytes,
+                                    (hipStream_t)stream);
+    if (rc) return rc;
+    return sgm_launch_pass("mccnn_sgm_pass", vol_hwd, side, n_jobs, D, H, W, rh, rw, p1, p2, q1, q2, scratch, scratch_bytes,
+                           (hipStream_t)stream);
+}
+
+// The two halves of mccnn_sgm_pass as calls of their own (round 6): the flag planes depend on the images, the direction
+// and the threshold only - a caller that advances the two volumes of a pair in separate launches (or on separate
+// streams) builds them once per direction and hands them to every pass.
+extern "C" int mccnn_sgm_flags(const float *image_left, const float *image_right, int D, int H, int W, int rh, int rw,
+                               float thr, void *flags, size_t flags_bytes, mccnn_stream_t stream)
+{
+    return sgm_launch_flags("mccnn_sgm_flags", image_left, image_right, D, H, W, rh, rw, thr, flags, flags_bytes,
+                            (hipStream_t)stream);
+}
+
+extern "C" int mccnn_sgm_pass_flagged(float *const *vol_hwd, const int *side, int n_jobs, int D, int H, int W, int rh, int rw,
+                                      float p1, float p2, float q1, float q2, const void *flags, size_t flags_bytes,
+                                      mccnn_stream_t stream)
+{
+    return sgm_launch_pass("mccnn_sgm_pass_flagged", vol_hwd, side, n_jobs, D, H, W, rh, rw, p1, p2, q1, q2, flags,
+                           flags_bytes, (hipStream_t)stream);
 }
 
 extern "C" int mccnn_sgm_first_pass(const float *image_left, const float *image_right, const float *const *vol_dhw,

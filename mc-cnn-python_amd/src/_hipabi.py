@@ -63,6 +63,9 @@ SIGNATURES = {
     "mccnn_sgm_scratch_bytes": (_sz, [_i, _i, _i]),
     "mccnn_sgm_pass": (_i, [_vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _i, _i, _i, _i, _i,
                             _f, _f, _f, _f, _f, _vp, _sz, _vp]),
+    "mccnn_sgm_flags": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
+    "mccnn_sgm_pass_flagged": (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _vp, _sz,
+                                    _vp]),
     "mccnn_sgm_first_pass": (_i, [_vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _i, _i,
                                   _i, _f, _f, _f, _f, _f, _vp, _sz, _vp]),
     "mccnn_wta": (_i, [_vp, _i, _i, _i, _vp, _vp]),

@@ -604,20 +604,48 @@ def sgm_pass_hwd(image_left, image_right, vols_hwd, sides, D, r, p1, p2, q1, q2,
 SGM_DIRECTIONS = ((0, 1), (0, -1), (-1, 0), (1, 0))  # right, left, up, bottom (pf:194-208)
 
 
+def sgm_flag_planes(image_left, image_right, D, sgm_D, out=None):
+    """The flag planes of all four directions (mccnn_sgm_flags: which pixels' intensity step along r reaches sgm_D,
+    pf:504-533), one buffer per direction: they depend on the images only, so a pair builds them once - off the critical
+    path - and every pass of both volumes reads them (sgm_average_hwd(flags=...))."""
+    H, W = image_left.shape
+    thr = _f32(sgm_D)
+    planes = out if out is not None else [sgm_scratch(H, W, D, image_left.device) for _ in SGM_DIRECTIONS]
+    for r, buf in zip(SGM_DIRECTIONS, planes):
+        hip.check(hip.load().mccnn_sgm_flags(hip.ptr(image_left), hip.ptr(image_right), int(D), H, W, int(r[0]), int(r[1]),
+                                             thr, hip.ptr(buf), buf.numel(), hip.stream()), "mccnn_sgm_flags")
+    return planes
+
+
+def sgm_pass_flagged_hwd(vols_hwd, sides, D, r, p1, p2, q1, q2, flags):
+    """One direction, in place on 1 or 2 HWD volumes, with the direction's flag planes already built (sgm_flag_planes)."""
+    H, W, _ = vols_hwd[0].shape
+    n = len(vols_hwd)
+    vol_arr = (ctypes.c_void_p * 2)(*([v.data_ptr() for v in vols_hwd] + [None] * (2 - n)))
+    side_arr = (ctypes.c_int * 2)(*(list(sides) + [0] * (2 - n)))
+    hip.check(hip.load().mccnn_sgm_pass_flagged(vol_arr, side_arr, n, int(D), H, W, int(r[0]), int(r[1]), p1, p2, q1, q2,
+                                                hip.ptr(flags), flags.numel(), hip.stream()), "mccnn_sgm_pass_flagged")
+
+
 def sgm_average_hwd(image_left, image_right, vols_hwd, sides, D, sgm_P1, sgm_P2, sgm_Q1, sgm_Q2, sgm_D, sgm_V,
-                    scratch, timer=_NO_TIMER):
+                    scratch, timer=_NO_TIMER, flags=None):
     """SGM_average (pf:187-235) on HWD volumes: the four passes compose in place (the reference aliases one array,
     pf:544,568) and its '(a+b+c+d)/4.' of four aliases of that array is the identity in binary floating point
-    (the CPU checker used by the tests evaluates it literally; the parity tests pin the equality)."""
+    (the CPU checker used by the tests evaluates it literally; the parity tests pin the equality).
+    flags: sgm_flag_planes() of the same images, D and sgm_D - the passes then launch no flag kernels of their own
+    (`scratch` is not used)."""
     p1h = _f32(sgm_P1)
     p1v = _f32(sgm_P1 / sgm_V)  # Python double division, rounded once (pf:204)
     p2, q1, q2, thr = _f32(sgm_P2), _f32(sgm_Q1), _f32(sgm_Q2), _f32(sgm_D)
-    for r in SGM_DIRECTIONS:
+    for i, r in enumerate(SGM_DIRECTIONS):
         # (a launch that advances ONE volume - the free-running chains of StereoMatcher - is priced apart from the
         # two-volume launch: half the bytes, and it runs beside whatever the other volume's chain is doing)
         timer.start("sgm_pass" if len(vols_hwd) == 2 else "sgm_pass_one_volume")
-        sgm_pass_hwd(image_left, image_right, vols_hwd, sides, D, r, p1h if r[0] == 0 else p1v, p2, q1, q2, thr,
-                     scratch)
+        if flags is not None:
+            sgm_pass_flagged_hwd(vols_hwd, sides, D, r, p1h if r[0] == 0 else p1v, p2, q1, q2, flags[i])
+        else:
+            sgm_pass_hwd(image_left, image_right, vols_hwd, sides, D, r, p1h if r[0] == 0 else p1v, p2, q1, q2, thr,
+                         scratch)
         timer.stop()
 
 
@@ -787,7 +815,7 @@ class StereoMatcher(object):
     def __init__(self, net, hp=None, cv_mode=hip.MCCNN_CV_EXACT, cbca_order=hip.MCCNN_CBCA_REFERENCE_ORDER,
                  feature_tile_rows=None, extras=None, features="auto", layout="auto", cbca_kernel="auto",
                  on_saturation="fallback", skip_unit_regions=True, two_chains=True, one_launch_builder=True,
-                 side_early=False, free_chains=True, refresh_first=True):
+                 side_early=False, free_chains=True, refresh_first=True, sgm_flags_once=True):
         self.device = hip.require_device()
         self.net = net
         self.hp = dict(DEFAULT_HP)
@@ -841,6 +869,9 @@ class StereoMatcher(object):
         # (match.py's first: 2 iterations) starts with a refresh launch and then skips to the end; False = round 5's rule
         # (its last launch is a full one)
         self.refresh_first = bool(refresh_first)
+        # the SGM flag planes of the four directions built once per pair on the side stream (mccnn_sgm_flags) and read by
+        # the passes of both chains; False = every one-volume pass launches its own flag kernel (8 per pair, on the chains)
+        self.sgm_flags_once = bool(sgm_flags_once)
         # opt-in departures from the reference (they change the output): the paper's rules it leaves out, and the
         # scalar promotion of the NumPy it was written for
         self.extras = dict(both_view_support=False, interpolation_directions=4, occlusion_from_left=False,
@@ -877,6 +908,7 @@ class StereoMatcher(object):
             ws = dict(
                 vol=[torch.empty((n,), dtype=torch.float32, device=dev) for _ in range(4)],
                 scratch=sgm_scratch(H, W, D, dev),
+                sgm_flags=[sgm_scratch(H, W, D, dev) for _ in SGM_DIRECTIONS],     # flag planes of the four directions
                 sup_l=support_buffer(H, W, dev), sup_r=support_buffer(H, W, dev),
                 status=torch.empty((H, W), dtype=torch.int32, device=dev),
                 maps=torch.empty((6, H, W), dtype=torch.float32, device=dev),   # dl, dr, interp, subpixel, median, out
@@ -952,12 +984,14 @@ class StereoMatcher(object):
         # everything beside the conv stack 9.19 / 9.12 (the builder's waves slow the matrix-core kernels down by what
         # they save), beside the cost volume 9.14 / 9.06.
         overlap = timer is _NO_TIMER
-        skip_ready = full_ready = sup_l = sup_r = None
+        skip_ready = full_ready = sup_l = sup_r = flag_planes = None
+        want_flags = (self.sgm_flags_once and self.free_chains and keep is None and ws["progs"] is not None
+                      and self.two_chains and self.pixel_major())
 
         def side_work(stage):
             """stage 0: support arms + both program sets (or, one_launch_builder=False, the full programs; stage 1: the
             skip programs)."""
-            nonlocal skip_ready, full_ready, sup_l, sup_r
+            nonlocal skip_ready, full_ready, sup_l, sup_r, flag_planes
             if self._side is None:
                 self._side = torch.cuda.Stream()
             self._side.wait_stream(torch.cuda.current_stream())
@@ -969,6 +1003,8 @@ class StereoMatcher(object):
                         # time either of the two earlier launches took)
                         cbca_prog_build_pair(sup_l, sup_r, D, hp["cbca_distance"], ws["progs"],
                                              "both" if (self.skip_unit_regions and self.one_launch_builder) else "full")
+                    if want_flags:
+                        flag_planes = sgm_flag_planes(L, R, D, hp["sgm_D"], out=ws["sgm_flags"])
                     full_ready = torch.cuda.Event()
                     full_ready.record(self._side)
                 elif ws["progs"] is not None and self.skip_unit_regions and not self.one_launch_builder:
@@ -1038,13 +1074,17 @@ class StereoMatcher(object):
             if free:
                 n1, n2 = int(hp["cbca_num_iterations1"]), int(hp["cbca_num_iterations2"])
                 fuse = n2 >= 1 and D <= cbca_hwd_wta_max_d()
-                if "scratch2" not in ws:
+                if flag_planes is None and self.sgm_flags_once:      # (per-stage timing: nothing ran beside the cost volume)
+                    timer.start("sgm_flags")
+                    flag_planes = sgm_flag_planes(L, R, D, hp["sgm_D"], out=ws["sgm_flags"])
+                    timer.stop()
+                if flag_planes is None and "scratch2" not in ws:
                     ws["scratch2"] = sgm_scratch(H, W, D, self.device)
                 main_s, right_s = torch.cuda.current_stream(), self._right_stream()
                 right_s.wait_stream(main_s)
                 ends = []
                 for st, v, t, sup, prog, side, scr in ((main_s, lh, as_hwd(b0), sup_l, progs[0], sides[0], ws["scratch"]),
-                                                       (right_s, rh, as_hwd(b1), sup_r, progs[1], sides[1], ws["scratch2"])):
+                                                       (right_s, rh, as_hwd(b1), sup_r, progs[1], sides[1], ws.get("scratch2"))):
                     with torch.cuda.stream(st):
                         # (the brackets are recorded on the chain's own stream: a stage's span beside the other chain)
                         timer.span_start("aggregation_1")
@@ -1053,8 +1093,11 @@ class StereoMatcher(object):
                                                skip_ready=skip_ready if overlap else None, timer=timer)
                         timer.span_stop("aggregation_1")
                         timer.span_start("sgm")
+                        # (the flag planes of the four directions were built once, on the side stream beside the cost
+                        # volume: both chains read them and launch no flag kernels of their own - 8 launches of 11 us
+                        # off the two critical chains)
                         sgm_average_hwd(L, R, [v], [side], D, hp["sgm_P1"], hp["sgm_P2"], hp["sgm_Q1"], hp["sgm_Q2"],
-                                        hp["sgm_D"], hp["sgm_V"], scr, timer)
+                                        hp["sgm_D"], hp["sgm_V"], scr, timer, flags=flag_planes)
                         timer.span_stop("sgm")
                         timer.span_start("aggregation_2")
                         v, t = cbca_prog_chain(v, t, sup, prog, D, n2 - 1 if fuse else n2, hp["cbca_distance"], total=n2,

@@ -326,3 +326,38 @@ def test_cost_volume_border_fill_special_values_against_the_oracle(sd, H, W, D):
     pl, pr = sd.cost_volume(dev(fl), dev(fr), D)
     assert_bits_strict(pl.cpu().numpy(), ol, "plane-major cost volume, special values (left)")
     assert_bits_strict(pr.cpu().numpy(), orr, "plane-major cost volume, special values (right)")
+
+
+@pytest.mark.parametrize("H,W,D", [(37, 61, 256), (20, 90, 192), (16, 70, 40), (12, 300, 400)])
+def test_sgm_flag_planes_built_once_equal_the_pass_that_builds_its_own(sd, H, W, D):
+    """mccnn_sgm_flags + mccnn_sgm_pass_flagged (the flag planes of a direction built once per pair and read by the passes
+    of both volumes, also when these run as separate one-volume launches) against mccnn_sgm_pass and against the CPU
+    checker's SGM_average (pf:187-235): every bit."""
+    import oracle as o
+    import synthetic
+    rng = np.random.default_rng(H + W + D)
+    L, R, _, _, _ = synthetic.make_pair(H, W, min(D, W - 2), seed=11)
+    l, r = dev(L[:, :, 0]), dev(R[:, :, 0])
+    vl = (-rng.random((D, H, W), dtype=np.float32)).astype(np.float32)
+    vr = (-rng.random((D, H, W), dtype=np.float32)).astype(np.float32)
+    hp = (2.3, 55.9, 4.0, 8.0, 0.08, 1.5)
+    want = o.SGM_average(vl.copy(), vr.copy(), L, R, *[x if i != 2 and i != 3 else int(x) for i, x in enumerate(hp)])
+    scratch = sd.sgm_scratch(H, W, D, l.device)
+    flags = sd.sgm_flag_planes(l, r, D, hp[4])
+    # two-volume launches on planes built once
+    a, b = sd.dhw_to_hwd(dev(vl)), sd.dhw_to_hwd(dev(vr))
+    sd.sgm_average_hwd(l, r, [a, b], [0, 1], D, *hp, None, flags=flags)
+    # one-volume launches, the two volumes on two streams, the same planes
+    c, d = sd.dhw_to_hwd(dev(vl)), sd.dhw_to_hwd(dev(vr))
+    s2 = torch.cuda.Stream()
+    s2.wait_stream(torch.cuda.current_stream())
+    sd.sgm_average_hwd(l, r, [c], [0], D, *hp, None, flags=flags)
+    with torch.cuda.stream(s2):
+        sd.sgm_average_hwd(l, r, [d], [1], D, *hp, None, flags=flags)
+    torch.cuda.current_stream().wait_stream(s2)
+    # the pass that builds its own planes
+    e, f = sd.dhw_to_hwd(dev(vl)), sd.dhw_to_hwd(dev(vr))
+    sd.sgm_average_hwd(l, r, [e, f], [0, 1], D, *hp, scratch)
+    for name, (x, y) in (("planes built once", (a, b)), ("one-volume launches on two streams", (c, d)), ("mccnn_sgm_pass", (e, f))):
+        assert_bits(sd.hwd_to_dhw(x, D).cpu().numpy(), want[0], "SGM_average, %s (left)" % name)
+        assert_bits(sd.hwd_to_dhw(y, D).cpu().numpy(), want[1], "SGM_average, %s (right)" % name)

@@ -34,8 +34,16 @@ def main():
         variants.append((a, kw))
     ms = {}
     ref = None
+    shared = None
     for name, kw in variants:
         m = sd.StereoMatcher(net, on_saturation="ignore", **kw)
+        # SHARE_WS=1: every variant runs on the FIRST matcher's workspace (the same buffers): identical matchers with
+        # workspaces of their own differ by up to 4 % (where the allocations happen to lie: profiles/r06_alloc_placement.txt)
+        if os.environ.get("SHARE_WS") == "1":
+            if shared is None:
+                shared = m.workspace(H, W, D)
+            else:
+                m._ws = {(H, W, D): shared}
         out = m.match_graph(dl, dr, D).clone()
         ref = out if ref is None else ref
         assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), name
