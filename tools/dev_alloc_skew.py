@@ -28,6 +28,10 @@ def main():
     dl, dr = torch.from_numpy(L[:, :, 0]).cuda(), torch.from_numpy(R[:, :, 0]).cuda()
     skews = [int(a) for a in sys.argv[1:]] or [0, 256, 4096, 65536, 1 << 20, (1 << 20) + 4096 + 256]
     variants = [("torch x4 (a)", None), ("torch x4 (b)", None)] + [("slab skew %d" % k, k) for k in skews] + [("torch x4 (c)", None)]
+    if os.environ.get("LOTTERY"):      # N matchers of either kind, created alternately: is one slab reliably better?
+        variants = []
+        for i in range(int(os.environ["LOTTERY"])):
+            variants += [("torch x4 #%d" % i, None), ("slab #%d" % i, 0)]
     ms, ref = {}, None
     for name, skew in variants:
         m = sd.StereoMatcher(net, on_saturation="ignore")
