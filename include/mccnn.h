@@ -45,7 +45,7 @@ extern "C" {
 
 typedef void *mccnn_stream_t; /* hipStream_t */
 
-#define MCCNN_ABI_VERSION 7 /* 2: window-mask plane, *_hwd entry points; 3: saturation flags; 4: program-driven CBCA; 5: skip programs; 6: one-volume launches; 7: refresh launches */
+#define MCCNN_ABI_VERSION 7 /* 2: window-mask plane, *_hwd entry points; 3: saturation flags; 4: program-driven CBCA; 5: skip programs; 6: one-volume launches; 7: refresh launches, SGM flag planes as a call of their own */
 
 #define MCCNN_E_INVALID (-1)     /* bad argument (null pointer, non-positive size, unsupported shape) */
 #define MCCNN_E_UNSUPPORTED (-2) /* shape outside what the kernels were built for (e.g. D > 512 for SGM) */
